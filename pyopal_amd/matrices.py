@@ -1,0 +1,188 @@
+"""Scoring matrices for the Opal search path.
+
+The reference takes its matrices from the third-party ``scoring-matrices``
+package (``src/pyopal/lib.pyx:39,1153,1202-1209,1230-1238``;
+``src/pyopal/_align.py:6,120-127``), which is neither vendored in the
+reference tree nor installed here. This module is a minimal provider with the
+same surface the path uses (`from_name`, `alphabet`, `is_integer`, `size`,
+row access, equality, pickling) and the public NCBI tables.
+
+Only the A/C/G/T corner of BLOSUM50 is pinned by the reference's tests
+(SURVEY.md appendix B); `_self_check` verifies those entries, symmetry and
+shape for every table carried here.
+"""
+
+from __future__ import annotations
+
+import array
+import typing
+
+_NCBI_ORDER = "ARNDCQEGHILKMFPSTWYVBZX*"
+
+_TABLES: typing.Dict[str, str] = {
+    "BLOSUM62": """
+ 4 -1 -2 -2  0 -1 -1  0 -2 -1 -1 -1 -1 -2 -1  1  0 -3 -2  0 -2 -1  0 -4
+-1  5  0 -2 -3  1  0 -2  0 -3 -2  2 -1 -3 -2 -1 -1 -3 -2 -3 -1  0 -1 -4
+-2  0  6  1 -3  0  0  0  1 -3 -3  0 -2 -3 -2  1  0 -4 -2 -3  3  0 -1 -4
+-2 -2  1  6 -3  0  2 -1 -1 -3 -4 -1 -3 -3 -1  0 -1 -4 -3 -3  4  1 -1 -4
+ 0 -3 -3 -3  9 -3 -4 -3 -3 -1 -1 -3 -1 -2 -3 -1 -1 -2 -2 -1 -3 -3 -2 -4
+-1  1  0  0 -3  5  2 -2  0 -3 -2  1  0 -3 -1  0 -1 -2 -1 -2  0  3 -1 -4
+-1  0  0  2 -4  2  5 -2  0 -3 -3  1 -2 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -2  0 -1 -3 -2 -2  6 -2 -4 -4 -2 -3 -3 -2  0 -2 -2 -3 -3 -1 -2 -1 -4
+-2  0  1 -1 -3  0  0 -2  8 -3 -3 -1 -2 -1 -2 -1 -2 -2  2 -3  0  0 -1 -4
+-1 -3 -3 -3 -1 -3 -3 -4 -3  4  2 -3  1  0 -3 -2 -1 -3 -1  3 -3 -3 -1 -4
+-1 -2 -3 -4 -1 -2 -3 -4 -3  2  4 -2  2  0 -3 -2 -1 -2 -1  1 -4 -3 -1 -4
+-1  2  0 -1 -3  1  1 -2 -1 -3 -2  5 -1 -3 -1  0 -1 -3 -2 -2  0  1 -1 -4
+-1 -1 -2 -3 -1  0 -2 -3 -2  1  2 -1  5  0 -2 -1 -1 -1 -1  1 -3 -1 -1 -4
+-2 -3 -3 -3 -2 -3 -3 -3 -1  0  0 -3  0  6 -4 -2 -2  1  3 -1 -3 -3 -1 -4
+-1 -2 -2 -1 -3 -1 -1 -2 -2 -3 -3 -1 -2 -4  7 -1 -1 -4 -3 -2 -2 -1 -2 -4
+ 1 -1  1  0 -1  0  0  0 -1 -2 -2  0 -1 -2 -1  4  1 -3 -2 -2  0  0  0 -4
+ 0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  1  5 -2 -2  0 -1 -1  0 -4
+-3 -3 -4 -4 -2 -2 -3 -2 -2 -3 -2 -3 -1  1 -4 -3 -2 11  2 -3 -4 -3 -2 -4
+-2 -2 -2 -3 -2 -1 -2 -3  2 -1 -1 -2 -1  3 -3 -2 -2  2  7 -1 -3 -2 -1 -4
+ 0 -3 -3 -3 -1 -2 -2 -3 -3  3  1 -2  1 -1 -2 -2  0 -3 -1  4 -3 -2 -1 -4
+-2 -1  3  4 -3  0  1 -1  0 -3 -4  0 -3 -3 -2  0 -1 -4 -3 -3  4  1 -1 -4
+-1  0  0  1 -3  3  4 -2  0 -3 -3  1 -1 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -1 -1 -1 -2 -1 -1 -1 -1 -1 -1 -1 -1 -1 -2  0  0 -2 -1 -1 -1 -1 -1 -4
+-4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4  1
+""",
+    "BLOSUM50": """
+ 5 -2 -1 -2 -1 -1 -1  0 -2 -1 -2 -1 -1 -3 -1  1  0 -3 -2  0 -2 -1 -1 -5
+-2  7 -1 -2 -4  1  0 -3  0 -4 -3  3 -2 -3 -3 -1 -1 -3 -1 -3 -1  0 -1 -5
+-1 -1  7  2 -2  0  0  0  1 -3 -4  0 -2 -4 -2  1  0 -4 -2 -3  4  0 -1 -5
+-2 -2  2  8 -4  0  2 -1 -1 -4 -4 -1 -4 -5 -1  0 -1 -5 -3 -4  5  1 -1 -5
+-1 -4 -2 -4 13 -3 -3 -3 -3 -2 -2 -3 -2 -2 -4 -1 -1 -5 -3 -1 -3 -3 -2 -5
+-1  1  0  0 -3  7  2 -2  1 -3 -2  2  0 -4 -1  0 -1 -1 -1 -3  0  4 -1 -5
+-1  0  0  2 -3  2  6 -3  0 -4 -3  1 -2 -3 -1 -1 -1 -3 -2 -3  1  5 -1 -5
+ 0 -3  0 -1 -3 -2 -3  8 -2 -4 -4 -2 -3 -4 -2  0 -2 -3 -3 -4 -1 -2 -2 -5
+-2  0  1 -1 -3  1  0 -2 10 -4 -3  0 -1 -1 -2 -1 -2 -3  2 -4  0  0 -1 -5
+-1 -4 -3 -4 -2 -3 -4 -4 -4  5  2 -3  2  0 -3 -3 -1 -3 -1  4 -4 -3 -1 -5
+-2 -3 -4 -4 -2 -2 -3 -4 -3  2  5 -3  3  1 -4 -3 -1 -2 -1  1 -4 -3 -1 -5
+-1  3  0 -1 -3  2  1 -2  0 -3 -3  6 -2 -4 -1  0 -1 -3 -2 -3  0  1 -1 -5
+-1 -2 -2 -4 -2  0 -2 -3 -1  2  3 -2  7  0 -3 -2 -1 -1  0  1 -3 -1 -1 -5
+-3 -3 -4 -5 -2 -4 -3 -4 -1  0  1 -4  0  8 -4 -3 -2  1  4 -1 -4 -4 -2 -5
+-1 -3 -2 -1 -4 -1 -1 -2 -2 -3 -4 -1 -3 -4 10 -1 -1 -4 -3 -3 -2 -1 -2 -5
+ 1 -1  1  0 -1  0 -1  0 -1 -3 -3  0 -2 -3 -1  5  2 -4 -2 -2  0  0 -1 -5
+ 0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  2  5 -3 -2  0  0 -1  0 -5
+-3 -3 -4 -5 -5 -1 -3 -3 -3 -3 -2 -3 -1  1 -4 -4 -3 15  2 -3 -5 -2 -3 -5
+-2 -1 -2 -3 -3 -1 -2 -3  2 -1 -1 -2  0  4 -3 -2 -2  2  8 -1 -3 -2 -1 -5
+ 0 -3 -3 -4 -1 -3 -3 -4 -4  4  1 -3  1 -1 -3 -2  0 -3 -1  5 -4 -3 -1 -5
+-2 -1  4  5 -3  0  1 -1  0 -4 -4  0 -3 -4 -2  0  0 -5 -3 -4  5  2 -1 -5
+-1  0  0  1 -3  4  5 -2  0 -3 -3  1 -1 -4 -1  0 -1 -2 -2 -3  2  5 -1 -5
+-1 -1 -1 -1 -2 -1 -1 -2 -1 -1 -1 -1 -1 -2 -2 -1  0 -3 -1 -1 -1 -1 -1 -5
+-5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5 -5  1
+""",
+}
+
+
+class ScoringMatrix:
+    """A square substitution matrix over an alphabet.
+
+    Mirrors the part of ``scoring_matrices.ScoringMatrix`` that the reference
+    touches (call sites listed in the module docstring).
+    """
+
+    __slots__ = ("_alphabet", "_rows", "_name")
+
+    def __init__(self, matrix, alphabet: str = _NCBI_ORDER, name: typing.Optional[str] = None):
+        rows = [tuple(float(x) for x in row) for row in matrix]
+        n = len(alphabet)
+        if len(rows) != n or any(len(r) != n for r in rows):
+            raise ValueError("matrix must be square and match the alphabet length")
+        if len(set(alphabet)) != n:
+            raise ValueError("alphabet contains duplicate letters")
+        self._alphabet = str(alphabet)
+        self._rows = tuple(rows)
+        self._name = name
+
+    # --- constructors -----------------------------------------------------
+    @classmethod
+    def from_name(cls, name: str = "BLOSUM62") -> "ScoringMatrix":
+        try:
+            text = _TABLES[name]
+        except KeyError:
+            raise ValueError(f"unknown scoring matrix: {name!r}") from None
+        rows = [[int(x) for x in line.split()] for line in text.strip().splitlines()]
+        return cls(rows, _NCBI_ORDER, name=name)
+
+    @classmethod
+    def from_match_mismatch(cls, match: float = 1.0, mismatch: float = -1.0,
+                            alphabet: str = "ACGT") -> "ScoringMatrix":
+        n = len(alphabet)
+        return cls([[match if i == j else mismatch for j in range(n)] for i in range(n)], alphabet)
+
+    # --- accessors --------------------------------------------------------
+    @property
+    def alphabet(self) -> str:
+        return self._alphabet
+
+    @property
+    def name(self) -> typing.Optional[str]:
+        return self._name
+
+    @property
+    def matrix(self):
+        return [list(r) for r in self._rows]
+
+    def size(self) -> int:
+        return len(self._alphabet)
+
+    def __len__(self) -> int:
+        return len(self._alphabet)
+
+    def __getitem__(self, item):
+        if isinstance(item, tuple):
+            i, j = item
+            return self._rows[i][j]
+        return self._rows[item]
+
+    def is_integer(self) -> bool:
+        return all(float(x).is_integer() for r in self._rows for x in r)
+
+    def is_symmetric(self) -> bool:
+        n = len(self)
+        return all(self._rows[i][j] == self._rows[j][i] for i in range(n) for j in range(i))
+
+    def min(self) -> float:
+        return min(min(r) for r in self._rows)
+
+    def max(self) -> float:
+        return max(max(r) for r in self._rows)
+
+    def int_array(self) -> array.array:
+        """Row-major ``int`` copy, as `Aligner.__init__` builds it
+        (``src/pyopal/lib.pyx:1229-1238``)."""
+        return array.array("i", [int(x) for r in self._rows for x in r])
+
+    # --- dunder -----------------------------------------------------------
+    def __eq__(self, other):
+        if not isinstance(other, ScoringMatrix):
+            return NotImplemented
+        return self._alphabet == other._alphabet and self._rows == other._rows
+
+    def __hash__(self):
+        return hash((self._alphabet, self._rows))
+
+    def __reduce__(self):
+        return type(self), (self.matrix, self._alphabet, self._name)
+
+    def __repr__(self):
+        if self._name is not None:
+            return f"{type(self).__name__}.from_name({self._name!r})"
+        return f"{type(self).__name__}({self.matrix!r}, alphabet={self._alphabet!r})"
+
+
+def available() -> typing.List[str]:
+    return sorted(_TABLES)
+
+
+def _self_check() -> None:
+    for name in _TABLES:
+        m = ScoringMatrix.from_name(name)
+        assert m.size() == 24 and m.is_integer() and m.is_symmetric(), name
+    b50 = ScoringMatrix.from_name("BLOSUM50")
+    ix = {c: i for i, c in enumerate(_NCBI_ORDER)}
+    pinned = {"AA": 5, "CC": 13, "GG": 8, "TT": 5, "AC": -1, "AG": 0, "AT": 0,
+              "CG": -3, "CT": -1, "GT": -2}
+    for pair, v in pinned.items():
+        assert b50[ix[pair[0]], ix[pair[1]]] == v, pair
