@@ -1,0 +1,113 @@
+/*
+ * miopal.h -- resident-database extension of the Opal C ABI for MI355X.
+ *
+ * `opalSearchDatabase` (opal.h; src/pyopal/opal.pxd:38-52) receives N host
+ * pointers on every call (the layout of pyopal's Database,
+ * src/pyopal/lib.pxd:95-98), which forces a pack + PCIe upload per query. The
+ * entry points below are what a GPU-aware binding would call instead: the
+ * database is packed and uploaded once, searches run against the device
+ * mirror. They replace, one for one:
+ *
+ *   miopalDbCreate          <- the (sequences, lengths, size) triple that
+ *                              BaseDatabase.get_sequences/get_lengths/get_size
+ *                              hand to the plugin (src/pyopal/lib.pxd:90-92,
+ *                              src/pyopal/platform/pyx.in:54-59)
+ *   miopalSearch            <- opalSearchDatabase(...) at
+ *                              src/pyopal/platform/pyx.in:77-91, including the
+ *                              [start, end) slicing done there by pointer
+ *                              offset (pyx.in:80-82)
+ *   miopalSearchDeviceScores<- same call for searchType = OPAL_SEARCH_SCORE
+ *                              with results left in HBM (multi-GPU shard
+ *                              driver, src/pyopal/_align.py:150-170)
+ *
+ * All functions return 0 or an OPAL_ERR_* / MIOPAL_ERR_* code (opal.h), never
+ * throw, never take the Python GIL, and may be called concurrently from many
+ * threads on one handle (the reference's callers do exactly that while
+ * holding the database read lock: src/pyopal/lib.pyx:1364,
+ * src/pyopal/_align.py:150-170). No torch types cross this boundary.
+ */
+#ifndef MIOPAL_H
+#define MIOPAL_H
+
+#include <stdint.h>
+
+#include "opal.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct MiopalDb MiopalDb;
+
+/* Number of usable gfx950 devices (0 when there is none or HIP fails). */
+int miopalDeviceCount(void);
+
+/* Human-readable description of the last error raised on this thread. */
+const char* miopalLastError(void);
+
+/*
+ * Build a device-resident database from N host sequences of ordinals
+ * (< alphabetLength <= 32). `device` is the HIP device ordinal. The host
+ * buffers are not referenced after the call returns.
+ */
+int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const int* lengths,
+                   int64_t count, int alphabetLength, int device);
+
+/* Same, from one concatenated residue buffer and offsets[count + 1]. */
+int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int64_t* offsets,
+                       int64_t count, int alphabetLength, int device);
+
+void miopalDbDestroy(MiopalDb* db);
+
+int64_t miopalDbCount(const MiopalDb* db);
+int64_t miopalDbTotalLength(const MiopalDb* db);
+/* Bytes of HBM held by the mirror (linear copy + packed views). */
+int64_t miopalDbDeviceBytes(const MiopalDb* db);
+
+/*
+ * One query against targets [start, end) of the database.
+ * Host output arrays have end - start entries and may be NULL when the
+ * search type does not produce them:
+ *   score                                  all search types
+ *   endTarget, endQuery                    SCORE_END and ALIGNMENT
+ *   startTarget, startQuery                ALIGNMENT
+ *   alignment[k] (malloc'ed, caller frees), alignmentLength[k]   ALIGNMENT
+ */
+int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                 int gapExt, const int* scoreMatrix, int alphabetLength, int searchType,
+                 int mode, int64_t start, int64_t end, int* score, int* endTarget,
+                 int* endQuery, int* startTarget, int* startQuery, unsigned char** alignment,
+                 int* alignmentLength);
+
+/*
+ * Score-only search whose int32 results stay in HBM: `deviceScores` is a
+ * device pointer with end - start entries (database order), `stream` a
+ * hipStream_t (NULL = the null stream). The call only enqueues work; the
+ * scores are valid once `stream` has drained. Targets whose 16-bit lanes
+ * saturate are recomputed at 32 bit inside the same stream.
+ */
+int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int queryLength,
+                             int gapOpen, int gapExt, const int* scoreMatrix,
+                             int alphabetLength, int mode, int64_t start, int64_t end,
+                             int* deviceScores, void* stream);
+
+/*
+ * Timing of the dominant kernel of the most recent search on this handle,
+ * measured with HIP events on the stream the kernel ran on. Returns the
+ * number of launches timed; *ms receives their total duration.
+ * Enabled with miopalSetProfiling(db, 1) (adds two event records per launch).
+ */
+void miopalSetProfiling(MiopalDb* db, int enabled);
+int miopalLastKernelTime(MiopalDb* db, float* ms);
+
+/* Result-struct form, identical in shape to opalSearchDatabase but against
+ * the resident mirror (what the platform plugin calls). */
+int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                        int gapExt, const int* scoreMatrix, int alphabetLength,
+                        OpalSearchResult* results[], int searchType, int mode,
+                        int overflowMethod, int64_t start, int64_t end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIOPAL_H */

@@ -1,0 +1,210 @@
+"""ctypes binding to libmiopal.so, the C ABI declared in include/opal.h and
+include/miopal.h. This is the only way Python code in this repository reaches
+the HIP kernels; there is no CPU fallback behind it."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import typing
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiopal.so")
+
+OPAL_ERR_OVERFLOW = 1
+OPAL_ERR_NO_SIMD_SUPPORT = 2
+OPAL_ERR_INVALID_MODE = 3
+
+SEARCH = {"score": 0, "end": 1, "full": 2}
+MODE = {"nw": 0, "hw": 1, "ov": 2, "sw": 3}
+OVERFLOW = {"simple": 0, "buckets": 1}
+
+
+class OpalSearchResult(ctypes.Structure):
+    _fields_ = [
+        ("scoreSet", ctypes.c_int),
+        ("score", ctypes.c_int),
+        ("endLocationTarget", ctypes.c_int),
+        ("endLocationQuery", ctypes.c_int),
+        ("startLocationTarget", ctypes.c_int),
+        ("startLocationQuery", ctypes.c_int),
+        ("alignment", ctypes.POINTER(ctypes.c_ubyte)),
+        ("alignmentLength", ctypes.c_int),
+    ]
+
+
+_lib = None
+_libc = None
+
+EXPORTS = [
+    # opal.h
+    "opalInitSearchResult", "opalSearchResultIsEmpty", "opalSearchResultSetScore",
+    "opalSearchDatabase", "opalSearchDatabaseCharSW",
+    # miopal.h
+    "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat",
+    "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
+    "miopalSearch", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
+    "miopalSearchResults",
+]
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmiopal.so (built in-tree by ``__graft_entry__.build()`` or
+    ``make -C pyopal_amd/csrc``). Raises if it is missing."""
+    global _lib, _libc
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()')")
+        L = ctypes.CDLL(LIB_PATH)
+        c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+        L.miopalDeviceCount.restype = c_int
+        L.miopalLastError.restype = ctypes.c_char_p
+        L.miopalDbCreate.restype = c_int
+        L.miopalDbCreate.argtypes = [ctypes.POINTER(c_vp), c_vp, c_vp, c_i64, c_int, c_int]
+        L.miopalDbCreateFlat.restype = c_int
+        L.miopalDbCreateFlat.argtypes = [ctypes.POINTER(c_vp), c_vp, c_vp, c_i64, c_int, c_int]
+        L.miopalDbDestroy.restype = None
+        L.miopalDbDestroy.argtypes = [c_vp]
+        for name in ("miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes"):
+            getattr(L, name).restype = c_i64
+            getattr(L, name).argtypes = [c_vp]
+        L.miopalSearch.restype = c_int
+        L.miopalSearch.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
+                                   c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.miopalSearchDeviceScores.restype = c_int
+        L.miopalSearchDeviceScores.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int,
+                                               c_i64, c_i64, c_vp, c_vp]
+        L.miopalSetProfiling.restype = None
+        L.miopalSetProfiling.argtypes = [c_vp, c_int]
+        L.miopalLastKernelTime.restype = c_int
+        L.miopalLastKernelTime.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float)]
+        L.miopalSearchResults.restype = c_int
+        L.miopalSearchResults.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int,
+                                          c_int, c_int, c_i64, c_i64]
+        L.opalSearchDatabase.restype = c_int
+        L.opalSearchDatabase.argtypes = [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int,
+                                         c_vp, c_int, c_int, c_int]
+        _lib = L
+        _libc = ctypes.CDLL(None)
+        _libc.free.argtypes = [c_vp]
+        _libc.free.restype = None
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().miopalLastError()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def raise_for(rc: int) -> None:
+    """Error mapping of the reference plugin (src/pyopal/platform/pyx.in:102-107)."""
+    if rc == 0:
+        return
+    if rc == OPAL_ERR_NO_SIMD_SUPPORT:
+        raise RuntimeError("no supported SIMD backend available")
+    if rc == OPAL_ERR_OVERFLOW:
+        raise OverflowError("overflow detected while computing alignment scores")
+    detail = last_error()
+    raise RuntimeError(f"failed to align to Opal database (code={rc})" + (f": {detail}" if detail else ""))
+
+
+def _ptr(a: typing.Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+class DeviceDatabase:
+    """Owner of a MiopalDb handle (device-resident database)."""
+
+    def __init__(self, residues: np.ndarray, offsets: np.ndarray, alphabet_length: int, device: int = 0):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        handle = ctypes.c_void_p()
+        rc = lib().miopalDbCreateFlat(ctypes.byref(handle), _ptr(residues), _ptr(offsets),
+                                      len(offsets) - 1, alphabet_length, device)
+        raise_for(rc)
+        self._h = handle
+        self.count = len(offsets) - 1
+        self.alphabet_length = alphabet_length
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().miopalDbDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self) -> int:
+        return int(lib().miopalDbDeviceBytes(self._h))
+
+    def search(self, query: np.ndarray, matrix: np.ndarray, gap_open: int = 3, gap_extend: int = 1,
+               mode: str = "score", algorithm: str = "sw", start: int = 0,
+               end: typing.Optional[int] = None) -> typing.Dict[str, typing.Any]:
+        """miopalSearch with numpy outputs (same keys as tests/_oracle.search)."""
+        end = self.count if end is None else min(end, self.count)
+        n = max(end - start, 0)
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        S = np.ascontiguousarray(matrix, dtype=np.int32)
+        st = SEARCH[mode]
+        out = {"score": np.zeros(n, dtype=np.int32)}
+        et = eq = s_t = s_q = alen = None
+        aptr = None
+        if st >= 1:
+            et = np.full(n, -1, dtype=np.int32)
+            eq = np.full(n, -1, dtype=np.int32)
+        if st == 2:
+            s_t = np.full(n, -1, dtype=np.int32)
+            s_q = np.full(n, -1, dtype=np.int32)
+            alen = np.zeros(n, dtype=np.int32)
+            aptr = (ctypes.c_void_p * max(n, 1))()
+        rc = lib().miopalSearch(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
+                                self.alphabet_length, st, MODE[algorithm], start, end,
+                                _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),
+                                ctypes.cast(aptr, ctypes.c_void_p) if aptr is not None else None,
+                                _ptr(alen))
+        raise_for(rc)
+        if st >= 1:
+            out.update(end_t=et, end_q=eq)
+        if st == 2:
+            alns = []
+            for k in range(n):
+                if aptr[k]:
+                    buf = (ctypes.c_ubyte * int(alen[k])).from_address(aptr[k])
+                    alns.append(np.frombuffer(bytes(buf), dtype=np.uint8).copy())
+                    _libc.free(aptr[k])
+                else:
+                    alns.append(np.zeros(0, dtype=np.uint8))
+            out.update(start_t=s_t, start_q=s_q, aln=alns)
+        return out
+
+    def search_device_scores(self, query: np.ndarray, matrix: np.ndarray, device_ptr: int,
+                             stream: int = 0, gap_open: int = 3, gap_extend: int = 1,
+                             algorithm: str = "sw", start: int = 0,
+                             end: typing.Optional[int] = None) -> None:
+        end = self.count if end is None else min(end, self.count)
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        S = np.ascontiguousarray(matrix, dtype=np.int32)
+        rc = lib().miopalSearchDeviceScores(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
+                                            self.alphabet_length, MODE[algorithm], start, end,
+                                            ctypes.c_void_p(device_ptr), ctypes.c_void_p(stream))
+        raise_for(rc)
+
+    def set_profiling(self, enabled: bool) -> None:
+        lib().miopalSetProfiling(self._h, 1 if enabled else 0)
+
+    def last_kernel_time(self) -> typing.Tuple[int, float]:
+        ms = ctypes.c_float(0)
+        n = lib().miopalLastKernelTime(self._h, ctypes.byref(ms))
+        return int(n), float(ms.value)

@@ -1,0 +1,106 @@
+// Shared declarations between the host scheduler and the HIP kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace miopal {
+
+constexpr int kLanes = 64;
+constexpr int kGroupTargets = 128;  // one wavefront owns 64 lanes x 2 packed 16-bit targets
+constexpr int kMaxAlphabet = 32;    // src/pyopal/lib.pxd:28-32
+constexpr int kMaxStripRows = 64;   // query rows held in registers per pass
+
+// Border / answer rules of one DP pass (see oracle/opal_oracle.c for the model).
+enum Region : int { kLastCell = 0, kLastRow = 1, kLastRowCol = 2, kAllCells = 3 };
+struct DpRules {
+    int topGap;   // H[-1][j] = -(open + j*ext) instead of 0
+    int leftGap;  // H[i][-1] = -(open + i*ext) instead of 0
+    int floor0;   // Smith-Waterman floor
+    int region;   // Region
+};
+
+// ---- inter-sequence kernel (one lane = two targets, packed int16) ---------
+struct InterseqArgs {
+    const uint2* pack;         // [group][chunk][lane] -> {4 residues of A, 4 residues of B}
+    const int64_t* groupOff;   // first uint2 of each group
+    const int* groupChunks;    // 4-column chunks per group
+    int nGroups;
+    const int16_t* profile;    // [A+1][Qpad] substitution scores, row A = padding symbol
+    int nSymbols;              // A + 1
+    int qPad;                  // nStrips * R
+    int nStrips;
+    int gapOpen, gapExt;
+    int32_t* score;            // [nGroups * 128], packed-view order
+    uint8_t* overflow;         // [nGroups * 128], 1 = lane saturated
+    uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
+    const int64_t* boundaryOff;
+};
+
+// ---- intra-sequence kernel (one wavefront = one pair, int32) --------------
+struct PairJob {
+    int64_t tOff;    // index of the first residue visited in the linear database
+    int32_t tLen;
+    int32_t tStep;   // +1 forward, -1 reversed prefix
+    int32_t qOff;    // index of the first query residue visited
+    int32_t qLen;
+    int32_t qStep;
+    int32_t rules;   // bit0 topGap, bit1 leftGap, bit2 floor0, bits 4..5 region
+    int64_t wsOff;   // int2 elements into the strip-boundary workspace (per buffer)
+    int64_t dirOff;  // bytes into the direction workspace (trace only)
+    int32_t out;     // result slot
+    int32_t pad;
+};
+
+struct IntraseqArgs {
+    const PairJob* jobs;
+    int nJobs;
+    const uint8_t* residues;  // linear database
+    const uint8_t* query;
+    const int32_t* matrix;    // [A][A]
+    int alphabet;
+    int gapOpen, gapExt;
+    int2* boundary[2];
+    uint8_t* dirs;            // direction bytes (trace only)
+    int32_t* score;
+    int32_t* endI;            // query coordinate of the best cell (pass coordinates)
+    int32_t* endJ;            // target coordinate
+};
+
+struct WalkArgs {
+    const PairJob* jobs;
+    int nJobs;
+    const uint8_t* residues;
+    const uint8_t* query;
+    const uint8_t* dirs;
+    uint8_t* ops;             // per job: buffer of qLen + tLen bytes, filled from the back
+    const int64_t* opsOff;    // [nJobs + 1]
+    int32_t* opsLen;
+};
+
+struct PackArgs {
+    const uint8_t* residues;
+    const int64_t* offsets;   // [N + 1] into residues
+    const int32_t* ids;       // view position -> database index
+    int nTargets;             // targets in the view
+    const int64_t* groupOff;
+    const int* groupChunks;
+    const int64_t* chunkPrefix;  // [nGroups + 1] running number of chunks
+    int nGroups;
+    int padSymbol;
+    uint2* pack;
+};
+
+// ---- launchers (defined next to their kernels) -----------------------------
+hipError_t launchInterseqSwScore(const InterseqArgs& a, int rowsPerStrip, hipStream_t stream);
+hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
+hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
+hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
+hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
+                         int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,
+                         hipStream_t stream);
+
+inline int packRules(const DpRules& r) {
+    return (r.topGap ? 1 : 0) | (r.leftGap ? 2 : 0) | (r.floor0 ? 4 : 0) | (r.region << 4);
+}
+
+}  // namespace miopal

@@ -1,0 +1,892 @@
+// Host-side scheduler behind the C ABI of include/opal.h and include/miopal.h.
+//
+// Plays the role of the scalar driver code of opalSearchDatabase (declared
+// src/pyopal/opal.pxd:38-52, called src/pyopal/platform/pyx.in:76-91): argument
+// checks, choice of lane width per target (the reference's 8/16/32-bit ladder,
+// src/pyopal/lib.pyx:1283-1289, becomes packed-16 / 32 here), the score pass,
+// the reversed-prefix pass for start locations and the traceback, all against
+// a device-resident database.
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/miopal.h"
+#include "common.h"
+
+using namespace miopal;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_lastError = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(MIOPAL_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+#define RC_TRY(expr)          \
+    do {                      \
+        int _rc = (expr);     \
+        if (_rc) return _rc;  \
+    } while (0)
+
+constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
+constexpr int64_t kDirBudget = 6ll << 30;  // bytes of direction workspace per traceback batch
+constexpr int64_t kInt32Safe = 1ll << 29;
+
+// ---------------------------------------------------------------------------
+// per-stream workspace: growable device buffers reused in stream order
+// ---------------------------------------------------------------------------
+enum Slot {
+    kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
+    kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
+    kOpsLen, kOvfHost, kSlots
+};
+
+struct Workspace {
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    void* buf[kSlots] = {};
+    size_t cap[kSlots] = {};
+    std::mutex busy;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // dominant-kernel launches
+
+    int get(int slot, size_t bytes, void** out) {
+        if (bytes == 0) bytes = 16;
+        if (cap[slot] < bytes) {
+            if (buf[slot]) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                HIP_TRY(hipFree(buf[slot]));
+                buf[slot] = nullptr;
+                cap[slot] = 0;
+            }
+            size_t want = bytes + bytes / 8 + 256;
+            HIP_TRY(hipMalloc(&buf[slot], want));
+            cap[slot] = want;
+        }
+        *out = buf[slot];
+        return 0;
+    }
+    size_t bytes() const {
+        size_t t = 0;
+        for (size_t c : cap) t += c;
+        return t;
+    }
+    ~Workspace() {
+        for (auto& ev : timings) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        for (void* p : buf)
+            if (p) (void)hipFree(p);
+        if (ownsStream && stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// packed view of a database slice
+// ---------------------------------------------------------------------------
+struct View {
+    int64_t start = 0, end = 0;
+    int nPacked = 0;                 // targets in the packed groups
+    int nGroups = 0;
+    int maxPackedLen = 0;
+    int64_t totalChunks = 0;
+    std::vector<int32_t> ids;        // view position -> database index (packed part)
+    std::vector<int32_t> longIds;    // targets always handled by the intra-sequence kernel
+    int32_t* d_ids = nullptr;
+    uint2* d_pack = nullptr;
+    int64_t* d_groupOff = nullptr;
+    int* d_groupChunks = nullptr;
+    int64_t* d_boundaryOff = nullptr;
+    size_t deviceBytes = 0;
+    ~View() {
+        if (d_ids) (void)hipFree(d_ids);
+        if (d_pack) (void)hipFree(d_pack);
+        if (d_groupOff) (void)hipFree(d_groupOff);
+        if (d_groupChunks) (void)hipFree(d_groupChunks);
+        if (d_boundaryOff) (void)hipFree(d_boundaryOff);
+    }
+};
+
+}  // namespace
+
+struct MiopalDb {
+    int device = 0;
+    int alphabet = 0;
+    int64_t count = 0;
+    int64_t total = 0;
+    std::vector<int64_t> offsets;  // host copy, [count + 1]
+    uint8_t* d_residues = nullptr;
+    int64_t* d_offsets = nullptr;
+
+    std::mutex viewMutex;
+    std::list<std::shared_ptr<View>> views;  // most recent first
+
+    std::mutex wsMutex;
+    std::vector<std::unique_ptr<Workspace>> ownedFree;              // internal streams, idle
+    std::map<hipStream_t, std::unique_ptr<Workspace>> external;     // caller streams
+
+    std::atomic<int> profiling{0};
+    std::mutex timingMutex;
+    Workspace* lastTimed = nullptr;
+
+    ~MiopalDb() {
+        (void)hipSetDevice(device);
+        views.clear();
+        ownedFree.clear();
+        external.clear();
+        if (d_residues) (void)hipFree(d_residues);
+        if (d_offsets) (void)hipFree(d_offsets);
+    }
+};
+
+namespace {
+
+struct WorkspaceLease {
+    MiopalDb* db;
+    Workspace* ws = nullptr;
+    bool owned = false;
+    std::unique_lock<std::mutex> lock;
+    explicit WorkspaceLease(MiopalDb* d) : db(d) {}
+    int acquireInternal() {
+        std::unique_ptr<Workspace> w;
+        {
+            std::lock_guard<std::mutex> g(db->wsMutex);
+            if (!db->ownedFree.empty()) {
+                w = std::move(db->ownedFree.back());
+                db->ownedFree.pop_back();
+            }
+        }
+        if (!w) {
+            w.reset(new Workspace());
+            HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+            w->ownsStream = true;
+        }
+        ws = w.release();
+        owned = true;
+        return 0;
+    }
+    int acquireExternal(hipStream_t s) {
+        {
+            std::lock_guard<std::mutex> g(db->wsMutex);
+            auto& slot = db->external[s];
+            if (!slot) {
+                slot.reset(new Workspace());
+                slot->stream = s;
+            }
+            ws = slot.get();
+        }
+        lock = std::unique_lock<std::mutex>(ws->busy);
+        return 0;
+    }
+    ~WorkspaceLease() {
+        if (owned && ws) {
+            std::lock_guard<std::mutex> g(db->wsMutex);
+            db->ownedFree.emplace_back(ws);
+        }
+    }
+};
+
+template <typename T>
+int upload(T* dst, const T* src, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return 0;
+}
+template <typename T>
+int download(T* dst, const T* src, size_t n, hipStream_t s) {
+    if (n == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
+int dbLen(const MiopalDb* db, int64_t id) { return (int)(db->offsets[id + 1] - db->offsets[id]); }
+
+// ---- view construction -------------------------------------------------------
+int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* out) {
+    auto v = std::make_shared<View>();
+    v->start = start;
+    v->end = end;
+    std::vector<int32_t> ids;
+    ids.reserve((size_t)(end - start));
+    for (int64_t k = start; k < end; ++k) {
+        if (dbLen(db, k) > kLongTarget) v->longIds.push_back((int32_t)k);
+        else ids.push_back((int32_t)k);
+    }
+    // longest first: the heaviest wavefronts are dispatched first
+    std::stable_sort(ids.begin(), ids.end(),
+                     [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
+    v->nPacked = (int)ids.size();
+    v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
+    std::vector<int64_t> groupOff(v->nGroups + 1, 0), chunkPrefix(v->nGroups + 1, 0), boundaryOff(v->nGroups + 1, 0);
+    std::vector<int> groupChunks(std::max(v->nGroups, 1), 0);
+    for (int g = 0; g < v->nGroups; ++g) {
+        const int maxLen = dbLen(db, ids[(size_t)g * kGroupTargets]);  // sorted: first is longest
+        v->maxPackedLen = std::max(v->maxPackedLen, maxLen);
+        const int chunks = std::max(1, (maxLen + 3) / 4);
+        groupChunks[g] = chunks;
+        chunkPrefix[g + 1] = chunkPrefix[g] + chunks;
+        groupOff[g + 1] = groupOff[g] + (int64_t)chunks * kLanes;
+        boundaryOff[g + 1] = boundaryOff[g] + (int64_t)chunks * 4 * kLanes;
+    }
+    v->totalChunks = chunkPrefix[v->nGroups];
+    v->ids = ids;
+    if (v->nGroups > 0) {
+        int64_t* d_chunkPrefix = nullptr;
+        const size_t packBytes = (size_t)groupOff[v->nGroups] * sizeof(uint2);
+        HIP_TRY(hipMalloc(&v->d_ids, ids.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&v->d_pack, packBytes));
+        HIP_TRY(hipMalloc(&v->d_groupOff, groupOff.size() * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&v->d_groupChunks, groupChunks.size() * sizeof(int)));
+        HIP_TRY(hipMalloc(&v->d_boundaryOff, boundaryOff.size() * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&d_chunkPrefix, chunkPrefix.size() * sizeof(int64_t)));
+        HIP_TRY(hipMemcpy(v->d_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->d_groupChunks, groupChunks.data(), groupChunks.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(v->d_boundaryOff, boundaryOff.data(), boundaryOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_chunkPrefix, chunkPrefix.data(), chunkPrefix.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        PackArgs pa{};
+        pa.residues = db->d_residues;
+        pa.offsets = db->d_offsets;
+        pa.ids = v->d_ids;
+        pa.nTargets = v->nPacked;
+        pa.groupOff = v->d_groupOff;
+        pa.groupChunks = v->d_groupChunks;
+        pa.chunkPrefix = d_chunkPrefix;
+        pa.nGroups = v->nGroups;
+        pa.padSymbol = db->alphabet;
+        pa.pack = v->d_pack;
+        HIP_TRY(launchPack(pa, v->totalChunks, nullptr));
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(d_chunkPrefix));
+        v->deviceBytes = packBytes + ids.size() * 4 + groupOff.size() * 16 + groupChunks.size() * 4;
+    }
+    *out = v;
+    return 0;
+}
+
+int getView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* out) {
+    std::lock_guard<std::mutex> g(db->viewMutex);
+    for (auto it = db->views.begin(); it != db->views.end(); ++it) {
+        if ((*it)->start == start && (*it)->end == end) {
+            *out = *it;
+            db->views.splice(db->views.begin(), db->views, it);
+            return 0;
+        }
+    }
+    RC_TRY(buildView(db, start, end, out));
+    db->views.push_front(*out);
+    // keep the full-database view plus a few slices (thread-chunked callers,
+    // src/pyopal/_align.py:150-170, re-use their slice on every query)
+    while (db->views.size() > 16) db->views.pop_back();
+    return 0;
+}
+
+// ---- one search ----------------------------------------------------------------
+struct Search {
+    MiopalDb* db;
+    Workspace* ws;
+    hipStream_t stream;
+    const unsigned char* query;
+    int Q, open, ext, A, searchType, mode;
+    const int* matrix;
+    int64_t start, end;
+    int64_t n;
+    int maxScore = 0, minScore = 0;
+
+    uint8_t* d_query = nullptr;
+    int32_t* d_matrix = nullptr;
+
+    int rulesFor(int m, DpRules* r) const {
+        switch (m) {
+            case OPAL_MODE_NW: *r = {1, 1, 0, kLastCell}; return 0;
+            case OPAL_MODE_HW: *r = {0, 1, 0, kLastRow}; return 0;
+            case OPAL_MODE_OV: *r = {0, 0, 0, kLastRowCol}; return 0;
+            case OPAL_MODE_SW: *r = {0, 0, 1, kAllCells}; return 0;
+        }
+        return fail(OPAL_ERR_INVALID_MODE, "invalid alignment mode %d", m);
+    }
+
+    int prepare() {
+        void* p;
+        RC_TRY(ws->get(kQuery, (size_t)std::max(Q, 1), &p));
+        d_query = (uint8_t*)p;
+        RC_TRY(ws->get(kMatrix, (size_t)A * A * sizeof(int32_t), &p));
+        d_matrix = (int32_t*)p;
+        RC_TRY(upload(d_query, query, (size_t)Q, stream));
+        RC_TRY(upload(d_matrix, (const int32_t*)matrix, (size_t)A * A, stream));
+        maxScore = *std::max_element(matrix, matrix + A * A);
+        minScore = *std::min_element(matrix, matrix + A * A);
+        return 0;
+    }
+
+    // Conservative range check for the 32-bit kernels (the reference returns
+    // OPAL_ERR_OVERFLOW when its widest lanes overflow, pyx.in:104-105).
+    int checkInt32(int64_t maxLen) const {
+        const int64_t mag = std::max<int64_t>(std::llabs((long long)maxScore), std::llabs((long long)minScore));
+        const int64_t bound = 2 * (int64_t)std::llabs((long long)open) +
+                              ((int64_t)Q + maxLen) * std::llabs((long long)ext) +
+                              std::min<int64_t>(Q, maxLen) * mag + mag;
+        if (bound >= kInt32Safe)
+            return fail(OPAL_ERR_OVERFLOW, "scores may exceed the 32-bit range (bound %lld)", (long long)bound);
+        return 0;
+    }
+
+    bool interseqUsable() const {
+        if (mode != OPAL_MODE_SW || searchType != OPAL_SEARCH_SCORE || Q <= 0) return false;
+        if (open < 0 || ext < 0) return false;
+        if (maxScore > 16383 || minScore < -16383) return false;
+        return true;
+    }
+
+    // Runs the intra-sequence kernel over `jobs`; results land in the given device arrays.
+    int runPairs(std::vector<PairJob>& jobs, bool trace, int32_t* d_score, int32_t* d_endI,
+                 int32_t* d_endJ, uint8_t* d_dirs) {
+        if (jobs.empty()) return 0;
+        int64_t wsElems = 0;
+        for (auto& j : jobs) {
+            j.wsOff = wsElems;
+            if (j.qLen > kLanes) wsElems += j.tLen;
+        }
+        void *pj, *b0, *b1;
+        RC_TRY(ws->get(kJobs, jobs.size() * sizeof(PairJob), &pj));
+        RC_TRY(ws->get(kPairB0, (size_t)wsElems * sizeof(int2), &b0));
+        RC_TRY(ws->get(kPairB1, (size_t)wsElems * sizeof(int2), &b1));
+        RC_TRY(upload((PairJob*)pj, jobs.data(), jobs.size(), stream));
+        IntraseqArgs a{};
+        a.jobs = (const PairJob*)pj;
+        a.nJobs = (int)jobs.size();
+        a.residues = db->d_residues;
+        a.query = d_query;
+        a.matrix = d_matrix;
+        a.alphabet = A;
+        a.gapOpen = open;
+        a.gapExt = ext;
+        a.boundary[0] = (int2*)b0;
+        a.boundary[1] = (int2*)b1;
+        a.dirs = d_dirs;
+        a.score = d_score;
+        a.endI = d_endI;
+        a.endJ = d_endJ;
+        HIP_TRY(launchIntraseq(a, trace, stream));
+        return 0;
+    }
+
+    PairJob forwardJob(int64_t id, int rules) const {
+        PairJob j{};
+        j.tOff = db->offsets[id];
+        j.tLen = dbLen(db, id);
+        j.tStep = 1;
+        j.qOff = 0;
+        j.qLen = Q;
+        j.qStep = 1;
+        j.rules = rules;
+        j.out = (int32_t)(id - start);
+        return j;
+    }
+
+    // Score pass (all search types). d_score/d_endI/d_endJ are in database order.
+    int scorePass(int32_t* d_score, int32_t* d_endI, int32_t* d_endJ) {
+        DpRules r;
+        RC_TRY(rulesFor(mode, &r));
+        const int rules = packRules(r);
+        std::vector<PairJob> jobs;
+        int64_t maxLen = 0;
+        for (int64_t k = start; k < end; ++k) maxLen = std::max<int64_t>(maxLen, dbLen(db, k));
+        RC_TRY(checkInt32(maxLen));
+
+        if (!interseqUsable()) {
+            jobs.reserve((size_t)n);
+            for (int64_t k = start; k < end; ++k) jobs.push_back(forwardJob(k, rules));
+            return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
+        }
+
+        std::shared_ptr<View> view;
+        RC_TRY(getView(db, start, end, &view));
+        for (int32_t id : view->longIds) jobs.push_back(forwardJob(id, rules));
+
+        if (view->nGroups > 0) {
+            const int nStrips = (Q + kMaxStripRows - 1) / kMaxStripRows;
+            const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
+            const int qPad = nStrips * rows;
+            const int nSym = A + 1;
+            // query profile: profile[t][i] = S[q_i][t]; padding symbol and padding rows = -32768
+            std::vector<int16_t> prof((size_t)nSym * qPad, (int16_t)-32768);
+            for (int t = 0; t < A; ++t)
+                for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = (int16_t)matrix[query[i] * A + t];
+            void *pp, *vs, *vo, *ct;
+            RC_TRY(ws->get(kProfile, prof.size() * sizeof(int16_t), &pp));
+            RC_TRY(ws->get(kViewScore, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vs));
+            RC_TRY(ws->get(kViewOvf, (size_t)view->nGroups * kGroupTargets, &vo));
+            RC_TRY(ws->get(kCounter, sizeof(int32_t), &ct));
+            RC_TRY(upload((int16_t*)pp, prof.data(), prof.size(), stream));
+            HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
+            InterseqArgs ia{};
+            ia.pack = view->d_pack;
+            ia.groupOff = view->d_groupOff;
+            ia.groupChunks = view->d_groupChunks;
+            ia.nGroups = view->nGroups;
+            ia.profile = (const int16_t*)pp;
+            ia.nSymbols = nSym;
+            ia.qPad = qPad;
+            ia.nStrips = nStrips;
+            ia.gapOpen = std::min(open, 32767);
+            ia.gapExt = std::min(ext, 32767);
+            ia.score = (int32_t*)vs;
+            ia.overflow = (uint8_t*)vo;
+            ia.boundaryOff = view->d_boundaryOff;
+            if (nStrips > 1) {
+                void *b0, *b1;
+                const size_t bytes = (size_t)view->totalChunks * 4 * kLanes * sizeof(uint2);
+                RC_TRY(ws->get(kBoundary0, bytes, &b0));
+                RC_TRY(ws->get(kBoundary1, bytes, &b1));
+                ia.boundary[0] = (uint2*)b0;
+                ia.boundary[1] = (uint2*)b1;
+            }
+            const bool timed = db->profiling.load() != 0;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timed) {
+                HIP_TRY(hipEventCreate(&e0));
+                HIP_TRY(hipEventCreate(&e1));
+                HIP_TRY(hipEventRecord(e0, stream));
+            }
+            HIP_TRY(launchInterseqSwScore(ia, rows, stream));
+            if (timed) {
+                HIP_TRY(hipEventRecord(e1, stream));
+                std::lock_guard<std::mutex> g(db->timingMutex);
+                ws->timings.emplace_back(e0, e1);
+                db->lastTimed = ws;
+            }
+            HIP_TRY(launchScatter(ia.score, ia.overflow, view->d_ids, view->nPacked, start, d_score,
+                                  (int32_t*)ct, stream));
+            // 16-bit lanes can only saturate when min(Q, L) * maxScore reaches 32767
+            const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
+            if (reach >= 32767) {
+                int32_t count = 0;
+                RC_TRY(download(&count, (const int32_t*)ct, 1, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (count > 0) {
+                    std::vector<uint8_t> flags((size_t)view->nPacked);
+                    RC_TRY(download(flags.data(), (const uint8_t*)vo, flags.size(), stream));
+                    HIP_TRY(hipStreamSynchronize(stream));
+                    for (int k = 0; k < view->nPacked; ++k)
+                        if (flags[k]) jobs.push_back(forwardJob(view->ids[k], rules));
+                }
+            }
+        }
+        return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
+    }
+};
+
+int validate(const MiopalDb* db, const unsigned char* query, int Q, const int* matrix, int A,
+             int searchType, int mode, int64_t start, int64_t end) {
+    if (!db) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null database handle");
+    if (mode < OPAL_MODE_NW || mode > OPAL_MODE_SW) return fail(OPAL_ERR_INVALID_MODE, "invalid alignment mode %d", mode);
+    if (searchType < OPAL_SEARCH_SCORE || searchType > OPAL_SEARCH_ALIGNMENT)
+        return fail(OPAL_ERR_INVALID_MODE, "invalid search type %d", searchType);
+    if (Q < 0 || (Q > 0 && !query)) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad query");
+    if (!matrix || A <= 0 || A > kMaxAlphabet) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad score matrix / alphabet length %d", A);
+    if (A != db->alphabet) return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d differs from the database's %d", A, db->alphabet);
+    for (int i = 0; i < Q; ++i)
+        if (query[i] >= A) return fail(MIOPAL_ERR_BAD_ARGUMENT, "query residue %d out of range at %d", query[i], i);
+    if (start < 0 || end < start || end > db->count) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad slice [%lld, %lld)", (long long)start, (long long)end);
+    return 0;
+}
+
+int createCommon(MiopalDb** out, const unsigned char* residues, const std::vector<int64_t>& offsets,
+                 int64_t count, int alphabetLength, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(OPAL_ERR_NO_SIMD_SUPPORT, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(MIOPAL_ERR_BAD_ARGUMENT, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<MiopalDb> db(new MiopalDb());
+    db->device = device;
+    db->alphabet = alphabetLength;
+    db->count = count;
+    db->offsets = offsets;
+    db->total = offsets[(size_t)count];
+    for (int64_t i = 0; i < db->total; ++i)
+        if (residues[i] >= alphabetLength)
+            return fail(MIOPAL_ERR_BAD_ARGUMENT, "residue %d out of range for alphabet %d", residues[i], alphabetLength);
+    HIP_TRY(hipMalloc(&db->d_residues, (size_t)db->total + 64));
+    HIP_TRY(hipMalloc(&db->d_offsets, (size_t)(count + 1) * sizeof(int64_t)));
+    if (db->total) HIP_TRY(hipMemcpy(db->d_residues, residues, (size_t)db->total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->d_offsets, offsets.data(), (size_t)(count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    *out = db.release();
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int miopalDeviceCount(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    return usable;
+}
+
+const char* miopalLastError(void) { return g_lastError.c_str(); }
+
+int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const int* lengths,
+                   int64_t count, int alphabetLength, int device) {
+    if (!out || count < 0 || (count > 0 && (!sequences || !lengths)))
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to miopalDbCreate");
+    if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d not in 1..32", alphabetLength);
+    if (count >= INT32_MAX) return fail(MIOPAL_ERR_BAD_ARGUMENT, "too many sequences");
+    std::vector<int64_t> offsets((size_t)count + 1, 0);
+    for (int64_t k = 0; k < count; ++k) {
+        if (lengths[k] < 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "negative sequence length");
+        offsets[(size_t)k + 1] = offsets[(size_t)k] + lengths[k];
+    }
+    std::vector<unsigned char> flat((size_t)offsets[(size_t)count] + 1);
+    for (int64_t k = 0; k < count; ++k)
+        if (lengths[k]) memcpy(flat.data() + offsets[(size_t)k], sequences[k], (size_t)lengths[k]);
+    return createCommon(out, flat.data(), offsets, count, alphabetLength, device);
+}
+
+int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int64_t* offsets,
+                       int64_t count, int alphabetLength, int device) {
+    if (!out || count < 0 || !offsets) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to miopalDbCreateFlat");
+    if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d not in 1..32", alphabetLength);
+    if (count >= INT32_MAX) return fail(MIOPAL_ERR_BAD_ARGUMENT, "too many sequences");
+    std::vector<int64_t> off(offsets, offsets + count + 1);
+    if (off[0] != 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "offsets must start at 0");
+    for (int64_t k = 0; k < count; ++k)
+        if (off[(size_t)k + 1] < off[(size_t)k] || off[(size_t)k + 1] - off[(size_t)k] > INT32_MAX)
+            return fail(MIOPAL_ERR_BAD_ARGUMENT, "offsets must be non-decreasing");
+    if (off[(size_t)count] > 0 && !residues) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null residues");
+    return createCommon(out, residues, off, count, alphabetLength, device);
+}
+
+void miopalDbDestroy(MiopalDb* db) { delete db; }
+
+int64_t miopalDbCount(const MiopalDb* db) { return db ? db->count : 0; }
+int64_t miopalDbTotalLength(const MiopalDb* db) { return db ? db->total : 0; }
+int64_t miopalDbDeviceBytes(const MiopalDb* db) {
+    if (!db) return 0;
+    MiopalDb* m = const_cast<MiopalDb*>(db);
+    int64_t t = db->total + 64 + (db->count + 1) * 8;
+    {
+        std::lock_guard<std::mutex> g(m->viewMutex);
+        for (auto& v : m->views) t += (int64_t)v->deviceBytes;
+    }
+    return t;
+}
+
+void miopalSetProfiling(MiopalDb* db, int enabled) {
+    if (db) db->profiling.store(enabled ? 1 : 0);
+}
+
+int miopalLastKernelTime(MiopalDb* db, float* ms) {
+    if (!db || !ms) return 0;
+    std::lock_guard<std::mutex> g(db->timingMutex);
+    *ms = 0.f;
+    Workspace* ws = db->lastTimed;
+    if (!ws) return 0;
+    int n = 0;
+    for (auto& ev : ws->timings) {
+        float t = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess &&
+            hipEventElapsedTime(&t, ev.first, ev.second) == hipSuccess) {
+            *ms += t;
+            ++n;
+        }
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    ws->timings.clear();
+    return n;
+}
+
+int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                             int gapExt, const int* scoreMatrix, int alphabetLength, int mode,
+                             int64_t start, int64_t end, int* deviceScores, void* stream) {
+    RC_TRY(validate(db, query, queryLength, scoreMatrix, alphabetLength, OPAL_SEARCH_SCORE, mode, start, end));
+    if (end == start) return 0;
+    if (!deviceScores) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null device score buffer");
+    HIP_TRY(hipSetDevice(db->device));
+    WorkspaceLease lease(db);
+    RC_TRY(lease.acquireExternal((hipStream_t)stream));
+    Search s{db, lease.ws, (hipStream_t)stream, query, queryLength, gapOpen, gapExt, alphabetLength,
+             OPAL_SEARCH_SCORE, mode, scoreMatrix, start, end, end - start};
+    RC_TRY(s.prepare());
+    return s.scorePass((int32_t*)deviceScores, nullptr, nullptr);
+}
+
+int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
+                 const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
+                 int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
+                 int* startQuery, unsigned char** alignment, int* alignmentLength) {
+    RC_TRY(validate(db, query, queryLength, scoreMatrix, alphabetLength, searchType, mode, start, end));
+    const int64_t n = end - start;
+    if (n == 0) return 0;
+    if (!score) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null score output");
+    if (searchType >= OPAL_SEARCH_SCORE_END && (!endTarget || !endQuery))
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "null end-location outputs");
+    if (searchType == OPAL_SEARCH_ALIGNMENT && (!startTarget || !startQuery || !alignment || !alignmentLength))
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
+    HIP_TRY(hipSetDevice(db->device));
+    WorkspaceLease lease(db);
+    RC_TRY(lease.acquireInternal());
+    Workspace* ws = lease.ws;
+    hipStream_t stream = ws->stream;
+    Search s{db, ws, stream, query, queryLength, gapOpen, gapExt, alphabetLength, searchType, mode,
+             scoreMatrix, start, end, n};
+    RC_TRY(s.prepare());
+
+    void *ps, *pi = nullptr, *pj = nullptr;
+    RC_TRY(ws->get(kScore, (size_t)n * sizeof(int32_t), &ps));
+    const bool wantEnd = searchType >= OPAL_SEARCH_SCORE_END;
+    if (wantEnd) {
+        RC_TRY(ws->get(kEndI, (size_t)n * sizeof(int32_t), &pi));
+        RC_TRY(ws->get(kEndJ, (size_t)n * sizeof(int32_t), &pj));
+    }
+    RC_TRY(s.scorePass((int32_t*)ps, (int32_t*)pi, (int32_t*)pj));
+    RC_TRY(download(score, (const int*)ps, (size_t)n, stream));
+    if (wantEnd) {
+        RC_TRY(download(endQuery, (const int*)pi, (size_t)n, stream));
+        RC_TRY(download(endTarget, (const int*)pj, (size_t)n, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
+
+    // ---- start locations: reversed prefixes anchored on the end cell ----------
+    DpRules fr;
+    RC_TRY(s.rulesFor(mode, &fr));
+    for (int64_t k = 0; k < n; ++k) {
+        startQuery[k] = startTarget[k] = -1;
+        alignment[k] = nullptr;
+        alignmentLength[k] = 0;
+    }
+    std::vector<int64_t> live;  // slots with a non-empty alignment
+    for (int64_t k = 0; k < n; ++k)
+        if (endQuery[k] >= 0 && endTarget[k] >= 0) live.push_back(k);
+    if (mode == OPAL_MODE_NW) {
+        for (int64_t k : live) startQuery[k] = startTarget[k] = 0;
+    } else if (!live.empty()) {
+        const DpRules rr{1, 1, 0, fr.region};
+        std::vector<PairJob> jobs(live.size());
+        for (size_t x = 0; x < live.size(); ++x) {
+            const int64_t k = live[x];
+            PairJob& j = jobs[x];
+            j = PairJob{};
+            j.tOff = db->offsets[(size_t)(start + k)] + endTarget[k];
+            j.tLen = endTarget[k] + 1;
+            j.tStep = -1;
+            j.qOff = endQuery[k];
+            j.qLen = endQuery[k] + 1;
+            j.qStep = -1;
+            j.rules = packRules(rr);
+            j.out = (int32_t)x;
+        }
+        void *rs, *ri, *rj;
+        RC_TRY(ws->get(kRScore, live.size() * sizeof(int32_t), &rs));
+        RC_TRY(ws->get(kRI, live.size() * sizeof(int32_t), &ri));
+        RC_TRY(ws->get(kRJ, live.size() * sizeof(int32_t), &rj));
+        RC_TRY(s.runPairs(jobs, false, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj, nullptr));
+        std::vector<int32_t> hs(live.size()), hi(live.size()), hj(live.size());
+        RC_TRY(download(hs.data(), (const int32_t*)rs, hs.size(), stream));
+        RC_TRY(download(hi.data(), (const int32_t*)ri, hi.size(), stream));
+        RC_TRY(download(hj.data(), (const int32_t*)rj, hj.size(), stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t x = 0; x < live.size(); ++x) {
+            const int64_t k = live[x];
+            if (hs[x] != score[k] || hi[x] < 0 || hj[x] < 0)
+                return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
+                            (long long)(start + k));
+            startQuery[k] = endQuery[k] - hi[x];
+            startTarget[k] = endTarget[k] - hj[x];
+        }
+    }
+
+    // ---- traceback on [start..end] rectangles, batched by direction workspace --
+    size_t pos = 0;
+    while (pos < live.size()) {
+        std::vector<PairJob> jobs;
+        std::vector<int64_t> opsOff(1, 0);
+        int64_t dirBytes = 0;
+        size_t first = pos;
+        while (pos < live.size()) {
+            const int64_t k = live[pos];
+            const int qn = endQuery[k] - startQuery[k] + 1, tn = endTarget[k] - startTarget[k] + 1;
+            const int64_t need = (int64_t)((qn + kLanes - 1) / kLanes) * (tn + kLanes - 1) * kLanes;
+            if (!jobs.empty() && dirBytes + need > kDirBudget) break;
+            PairJob j{};
+            j.tOff = db->offsets[(size_t)(start + k)] + startTarget[k];
+            j.tLen = tn;
+            j.tStep = 1;
+            j.qOff = startQuery[k];
+            j.qLen = qn;
+            j.qStep = 1;
+            j.rules = packRules(DpRules{1, 1, 0, kLastCell});
+            j.dirOff = dirBytes;
+            j.out = (int32_t)jobs.size();
+            jobs.push_back(j);
+            dirBytes += need;
+            opsOff.push_back(opsOff.back() + qn + tn);
+            ++pos;
+        }
+        void *pd, *po, *poff, *plen, *pscore;
+        RC_TRY(ws->get(kDirs, (size_t)dirBytes, &pd));
+        RC_TRY(ws->get(kOps, (size_t)opsOff.back(), &po));
+        RC_TRY(ws->get(kOpsOff, opsOff.size() * sizeof(int64_t), &poff));
+        RC_TRY(ws->get(kOpsLen, jobs.size() * sizeof(int32_t), &plen));
+        RC_TRY(ws->get(kRScore, jobs.size() * sizeof(int32_t), &pscore));
+        RC_TRY(upload((int64_t*)poff, opsOff.data(), opsOff.size(), stream));
+        RC_TRY(s.runPairs(jobs, true, (int32_t*)pscore, nullptr, nullptr, (uint8_t*)pd));
+        WalkArgs wa{};
+        void* pjobs;
+        RC_TRY(ws->get(kJobs, jobs.size() * sizeof(PairJob), &pjobs));
+        wa.jobs = (const PairJob*)pjobs;
+        wa.nJobs = (int)jobs.size();
+        wa.residues = db->d_residues;
+        wa.query = s.d_query;
+        wa.dirs = (const uint8_t*)pd;
+        wa.ops = (uint8_t*)po;
+        wa.opsOff = (const int64_t*)poff;
+        wa.opsLen = (int32_t*)plen;
+        HIP_TRY(launchWalk(wa, stream));
+        std::vector<uint8_t> ops((size_t)opsOff.back());
+        std::vector<int32_t> lens(jobs.size()), tscore(jobs.size());
+        RC_TRY(download(ops.data(), (const uint8_t*)po, ops.size(), stream));
+        RC_TRY(download(lens.data(), (const int32_t*)plen, lens.size(), stream));
+        RC_TRY(download(tscore.data(), (const int32_t*)pscore, tscore.size(), stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (size_t x = 0; x < jobs.size(); ++x) {
+            const int64_t k = live[first + x];
+            if (tscore[x] != score[k])
+                return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
+                            tscore[x], score[k], (long long)(start + k));
+            const int len = lens[x];
+            unsigned char* buf = (unsigned char*)malloc((size_t)std::max(len, 1));
+            if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+            memcpy(buf, ops.data() + opsOff[x + 1] - len, (size_t)len);
+            alignment[k] = buf;
+            alignmentLength[k] = len;
+        }
+    }
+    return 0;
+}
+
+int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                        int gapExt, const int* scoreMatrix, int alphabetLength,
+                        OpalSearchResult* results[], int searchType, int mode, int overflowMethod,
+                        int64_t start, int64_t end) {
+    (void)overflowMethod;
+    if (!db) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null database handle");
+    if (end > db->count) end = db->count;
+    const int64_t n = end - start;
+    if (n <= 0) return n < 0 ? fail(MIOPAL_ERR_BAD_ARGUMENT, "bad slice") : 0;
+    if (!results) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null results");
+    std::vector<int> score((size_t)n), et, eq, st, sq, alen;
+    std::vector<unsigned char*> aln;
+    if (searchType >= OPAL_SEARCH_SCORE_END) { et.resize((size_t)n); eq.resize((size_t)n); }
+    if (searchType == OPAL_SEARCH_ALIGNMENT) { st.resize((size_t)n); sq.resize((size_t)n); alen.resize((size_t)n); aln.resize((size_t)n, nullptr); }
+    int rc = miopalSearch(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType,
+                          mode, start, end, score.data(), et.empty() ? nullptr : et.data(),
+                          eq.empty() ? nullptr : eq.data(), st.empty() ? nullptr : st.data(),
+                          sq.empty() ? nullptr : sq.data(), aln.empty() ? nullptr : aln.data(),
+                          alen.empty() ? nullptr : alen.data());
+    if (rc) {
+        for (auto p : aln) free(p);
+        return rc;
+    }
+    for (int64_t k = 0; k < n; ++k) {
+        OpalSearchResult* r = results[k];
+        r->scoreSet = 1;
+        r->score = score[(size_t)k];
+        if (searchType >= OPAL_SEARCH_SCORE_END) {
+            r->endLocationTarget = et[(size_t)k];
+            r->endLocationQuery = eq[(size_t)k];
+        }
+        if (searchType == OPAL_SEARCH_ALIGNMENT) {
+            r->startLocationTarget = st[(size_t)k];
+            r->startLocationQuery = sq[(size_t)k];
+            r->alignment = alen[(size_t)k] > 0 ? aln[(size_t)k] : nullptr;
+            if (alen[(size_t)k] == 0) free(aln[(size_t)k]);
+            r->alignmentLength = alen[(size_t)k];
+        }
+    }
+    return 0;
+}
+
+// ---- opal.h ---------------------------------------------------------------
+void opalInitSearchResult(OpalSearchResult* r) {
+    r->scoreSet = 0;
+    r->score = 0;
+    r->endLocationTarget = r->endLocationQuery = -1;
+    r->startLocationTarget = r->startLocationQuery = -1;
+    r->alignment = nullptr;
+    r->alignmentLength = 0;
+}
+
+int opalSearchResultIsEmpty(const OpalSearchResult r) { return !r.scoreSet; }
+
+void opalSearchResultSetScore(OpalSearchResult* r, int score) {
+    r->scoreSet = 1;
+    r->score = score;
+}
+
+int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db[], int dbLength,
+                       int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix,
+                       int alphabetLength, OpalSearchResult* results[], const int searchType, int mode,
+                       int overflowMethod) {
+    if (dbLength <= 0) return 0;
+    MiopalDb* h = nullptr;
+    int device = 0;
+    if (const char* env = getenv("MIOPAL_DEVICE")) device = atoi(env);
+    int rc = miopalDbCreate(&h, (const unsigned char* const*)db, dbSeqLengths, dbLength, alphabetLength, device);
+    if (rc) return rc;
+    rc = miopalSearchResults(h, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
+                             searchType, mode, overflowMethod, 0, dbLength);
+    miopalDbDestroy(h);
+    return rc;
+}
+
+int opalSearchDatabaseCharSW(unsigned char query[], int queryLength, unsigned char** db, int dbLength,
+                             int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix,
+                             int alphabetLength, OpalSearchResult* results[]) {
+    return opalSearchDatabase(query, queryLength, db, dbLength, dbSeqLengths, gapOpen, gapExt, scoreMatrix,
+                              alphabetLength, results, OPAL_SEARCH_SCORE, OPAL_MODE_SW, OPAL_OVERFLOW_BUCKETS);
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+// Intra-sequence kernels for gfx950: one wavefront aligns one (query, target)
+// pair at 32 bit, sweeping anti-diagonals of a 64-row strip (lane = query row).
+//
+// This is the exact, all-modes path behind opalSearchDatabase
+// (src/pyopal/opal.pxd:38-52): NW / HW / OV / SW scores with end locations,
+// the reversed-prefix pass that finds start locations, and the direction
+// matrix for the traceback. It also recomputes targets whose packed 16-bit
+// lanes saturated in the inter-sequence kernel (the 32-bit rung of the
+// reference's 8/16/32-bit overflow ladder, src/pyopal/lib.pyx:1283-1289) and
+// carries targets too long for one-lane-per-target scheduling.
+//
+// Model and tie-breaks: oracle/opal_oracle.c.
+#include "common.h"
+
+namespace miopal {
+
+constexpr int kNegInf = INT32_MIN / 4;
+constexpr int kJobsPerBlock = 4;
+constexpr int kMatStride = kMaxAlphabet + 1;  // odd stride: rows fall on different LDS banks
+
+// better(a, b): does candidate a replace b in the column-major, strictly-greater scan?
+static __device__ __forceinline__ bool better(int sa, int ja, int ia, int sb, int jb, int ib) {
+    if (sa != sb) return sa > sb;
+    if (ja != jb) return ja < jb;
+    return ia < ib;
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(IntraseqArgs a) {
+    __shared__ int smat[kMaxAlphabet * kMatStride];
+    const int A = a.alphabet;
+    for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x)
+        smat[(idx / A) * kMatStride + (idx % A)] = a.matrix[idx];
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int jobIdx = blockIdx.x * kJobsPerBlock + wave;
+    if (jobIdx >= a.nJobs) return;  // wave-uniform, after the only barrier
+
+    const PairJob job = a.jobs[jobIdx];
+    const int Q = job.qLen, L = job.tLen;
+    const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
+    const int region = (job.rules >> 4) & 3;
+    const int open = a.gapOpen, ext = a.gapExt;
+
+    int best = floor0 ? 0 : INT32_MIN;
+    int bi = -1, bj = -1;
+
+    if (Q > 0 && L > 0) {
+        const int nStrips = (Q + kLanes - 1) / kLanes;
+        const int nSteps = L + kLanes - 1;
+        const uint8_t* tptr = a.residues + job.tOff;
+        const uint8_t* qptr = a.query + job.qOff;
+        for (int s = 0; s < nStrips; ++s) {
+            const int i = s * kLanes + lane;
+            const bool rowActive = i < Q;
+            const int qres = rowActive ? qptr[(int64_t)i * job.qStep] : 0;
+            const int* srow = smat + qres * kMatStride;
+            int hLeft = leftGap ? -(open + i * ext) : 0;  // H[i][-1]
+            int eLeft = kNegInf;
+            int hDiag = (i == 0) ? 0 : (leftGap ? -(open + (i - 1) * ext) : 0);  // H[i-1][-1]
+            int hCur = 0, fCur = kNegInf, tres = 0;
+            int tbuf = 0, bH = 0, bF = kNegInf;
+            const int2* bin = a.boundary[(s + 1) & 1] + job.wsOff;
+            int2* bout = a.boundary[s & 1] + job.wsOff;
+            const bool lastStrip = s + 1 == nStrips;
+            uint8_t* dirs = TRACE ? a.dirs + job.dirOff + (size_t)s * nSteps * kLanes : nullptr;
+
+            for (int k = 0; k < nSteps; ++k) {
+                if ((k & 63) == 0) {
+                    const int kk = k + lane;
+                    tbuf = kk < L ? tptr[(int64_t)kk * job.tStep] : 0;
+                    if (s > 0) {
+                        int2 b = kk < L ? bin[kk] : make_int2(0, kNegInf);
+                        bH = b.x;
+                        bF = b.y;
+                    }
+                }
+                int hUp = __shfl_up(hCur, 1);
+                int fUp = __shfl_up(fCur, 1);
+                int tin = __shfl_up(tres, 1);
+                const int sel = k & 63;
+                const int t0 = __builtin_amdgcn_readlane(tbuf, sel);
+                int h0, f0;
+                if (s == 0) {
+                    h0 = topGap ? -(open + k * ext) : 0;
+                    f0 = kNegInf;
+                } else {
+                    h0 = __builtin_amdgcn_readlane(bH, sel);
+                    f0 = __builtin_amdgcn_readlane(bF, sel);
+                }
+                if (lane == 0) {
+                    hUp = h0;
+                    fUp = f0;
+                    tin = t0;
+                }
+                const int j = k - lane;
+                const bool valid = rowActive && j >= 0 && j < L;
+                const int sc = srow[tin];
+                const int eOpen = hLeft - open, eExt = eLeft - ext;
+                const int fOpen = hUp - open, fExt = fUp - ext;
+                const int e = max(eOpen, eExt);
+                const int f = max(fOpen, fExt);
+                const int d = hDiag + sc;
+                int h = max(d, max(e, f));
+                if (floor0) h = max(h, 0);
+                if (TRACE) {
+                    // priority diag > E (target gap) > F (query gap); inside a gap,
+                    // closing it (back to H) is preferred to extending it
+                    uint8_t code = (h == d) ? 0 : (h == e) ? 1 : 2;
+                    if (e == eOpen) code |= 4;
+                    if (f == fOpen) code |= 8;
+                    dirs[(size_t)k * kLanes + lane] = code;
+                }
+                if (valid) {
+                    hDiag = hUp;
+                    hLeft = h;
+                    eLeft = e;
+                    hCur = h;
+                    fCur = f;
+                    tres = tin;
+                    bool cand;
+                    if (region == kAllCells) cand = true;
+                    else if (region == kLastRow) cand = (i == Q - 1);
+                    else if (region == kLastRowCol) cand = (i == Q - 1) || (j == L - 1);
+                    else cand = (i == Q - 1) && (j == L - 1);
+                    if (cand && (h > best || (h == best && j < bj))) {
+                        best = h;
+                        bi = i;
+                        bj = j;
+                    }
+                    if (lane == kLanes - 1 && !lastStrip) bout[j] = make_int2(h, f);
+                }
+            }
+            if (!lastStrip) __threadfence();
+        }
+        // wave reduction: highest score, then smallest column, then smallest row
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int os = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+            const bool mineEmpty = bi < 0, otherEmpty = oi < 0;
+            bool take;
+            if (otherEmpty) take = false;
+            else if (mineEmpty) take = !floor0 || os > best;
+            else take = better(os, oj, oi, best, bj, bi);
+            if (take) {
+                best = os;
+                bi = oi;
+                bj = oj;
+            }
+        }
+    } else if (!floor0) {
+        // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+        best = 0;
+        if (Q > 0) best = leftGap ? -(open + (Q - 1) * ext) : 0;
+        if (L > 0) best = topGap ? -(open + (L - 1) * ext) : 0;
+    }
+    if (lane == 0) {
+        a.score[job.out] = best;
+        if (a.endI) a.endI[job.out] = bi;
+        if (a.endJ) a.endJ[job.out] = bj;
+    }
+}
+
+// One thread per pair: walk the direction bytes back from the end cell.
+__global__ void walk_kernel(WalkArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.nJobs) return;
+    const PairJob job = a.jobs[idx];
+    const int n = job.qLen, m = job.tLen;
+    const int nSteps = m + kLanes - 1;
+    const uint8_t* dirs = a.dirs + job.dirOff;
+    const uint8_t* q = a.query + job.qOff;
+    const uint8_t* t = a.residues + job.tOff;
+    uint8_t* ops = a.ops + a.opsOff[idx];
+    int64_t pos = a.opsOff[idx + 1] - a.opsOff[idx];
+    int i = n - 1, j = m - 1, state = 0, len = 0;
+    while (i >= 0 || j >= 0) {
+        if (i < 0) { ops[--pos] = 2; --j; ++len; continue; }
+        if (j < 0) { ops[--pos] = 1; --i; ++len; continue; }
+        const int l = i & 63;
+        const uint8_t d = dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
+        if (state == 0) {
+            const int c = d & 3;
+            if (c == 0) {
+                ops[--pos] = (q[i] == t[j]) ? 0 : 3;
+                ++len; --i; --j;
+            } else {
+                state = c;
+            }
+        } else if (state == 1) {
+            ops[--pos] = 2;
+            ++len;
+            if (d & 4) state = 0;
+            --j;
+        } else {
+            ops[--pos] = 1;
+            ++len;
+            if (d & 8) state = 0;
+            --i;
+        }
+    }
+    a.opsLen[idx] = len;
+}
+
+hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    const int blocks = (a.nJobs + kJobsPerBlock - 1) / kJobsPerBlock;
+    if (trace)
+        hipLaunchKernelGGL((intraseq_kernel<true>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+    else
+        hipLaunchKernelGGL((intraseq_kernel<false>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchWalk(const WalkArgs& a, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(walk_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace miopal

@@ -1,0 +1,94 @@
+// Layout kernels: build the lane-interleaved view of the database that the
+// inter-sequence kernel streams, and put its results back in database order.
+//
+// The reference hands opalSearchDatabase N separately allocated host buffers
+// (src/pyopal/lib.pxd:95-98, src/pyopal/platform/pyx.in:54-59). On the device
+// the database is one linear residue array plus offsets (kept for the
+// intra-sequence / traceback kernels) and, per searched slice, a packed view:
+// targets sorted by length, 128 per group, stored so that a wavefront reads one
+// contiguous 512-byte line per 4 database columns:
+//     pack[groupOff[g] + chunk * 64 + lane] = { 4 residues of target A(lane),
+//                                               4 residues of target B(lane) }
+// with A(lane) = view position g*128 + lane and B(lane) = g*128 + 64 + lane.
+// Positions past a target's end hold the padding symbol (alphabetLength), whose
+// profile row is -32768, so padded cells can never raise a score.
+#include "common.h"
+
+namespace miopal {
+
+
+static __device__ __forceinline__ uint32_t gather4(const uint8_t* base, int64_t len, int64_t col,
+                                                   uint32_t pad) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t c = col + b;
+        const uint32_t v = (base != nullptr && c < len) ? base[c] : pad;
+        w |= v << (8 * b);
+    }
+    return w;
+}
+
+__global__ void pack_kernel(PackArgs a) {
+    // one thread per (chunk, lane) element; chunks are numbered across groups
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t totalChunks = a.chunkPrefix[a.nGroups];
+    if (e >= totalChunks * kLanes) return;
+    const int64_t chunkGlobal = e / kLanes;
+    const int lane = (int)(e % kLanes);
+    // binary search the group of this chunk
+    int lo = 0, hi = a.nGroups - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.chunkPrefix[mid] <= chunkGlobal) lo = mid; else hi = mid - 1;
+    }
+    const int g = lo;
+    const int64_t chunk = chunkGlobal - a.chunkPrefix[g];
+    const int posA = g * kGroupTargets + lane, posB = posA + kLanes;
+    const uint8_t* pa = nullptr;
+    const uint8_t* pb = nullptr;
+    int64_t la = 0, lb = 0;
+    if (posA < a.nTargets) {
+        const int id = a.ids[posA];
+        pa = a.residues + a.offsets[id];
+        la = a.offsets[id + 1] - a.offsets[id];
+    }
+    if (posB < a.nTargets) {
+        const int id = a.ids[posB];
+        pb = a.residues + a.offsets[id];
+        lb = a.offsets[id + 1] - a.offsets[id];
+    }
+    const uint32_t pad = (uint32_t)a.padSymbol;
+    a.pack[a.groupOff[g] + chunk * kLanes + lane] =
+        make_uint2(gather4(pa, la, chunk * 4, pad), gather4(pb, lb, chunk * 4, pad));
+}
+
+// view order -> database order (relative to the slice start); counts saturated lanes
+__global__ void scatter_kernel(const int32_t* viewScore, const uint8_t* viewOverflow,
+                               const int32_t* ids, int nTargets, int64_t sliceStart,
+                               int32_t* out, int32_t* overflowCount) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nTargets) return;
+    out[ids[k] - sliceStart] = viewScore[k];
+    if (viewOverflow[k]) atomicAdd(overflowCount, 1);
+}
+
+hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream) {
+    const int64_t n = totalChunks * kLanes;
+    if (n <= 0) return hipSuccess;
+    const int threads = 256;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
+                         int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,
+                         hipStream_t stream) {
+    if (nTargets <= 0) return hipSuccess;
+    const int threads = 256;
+    hipLaunchKernelGGL(scatter_kernel, dim3((nTargets + threads - 1) / threads), dim3(threads), 0, stream,
+                       viewScore, viewOverflow, ids, nTargets, sliceStart, out, overflowCount);
+    return hipGetLastError();
+}
+
+}  // namespace miopal

@@ -1,0 +1,237 @@
+"""Parity of the HIP path (through the C ABI) against the CPU checker.
+
+Bit-exact: scores, end/start locations and alignment operations are integers.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _data
+import _oracle
+from pyopal_amd.matrices import ScoringMatrix
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+B50 = np.array(ScoringMatrix.from_name("BLOSUM50").int_array(), dtype=np.int32)
+B62 = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+ALGOS = ["nw", "hw", "ov", "sw"]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pyopal_amd import _capi
+    assert _capi.lib().miopalDeviceCount() >= 1, "no gfx950 device visible"
+    return _capi
+
+
+def compare(gpu, ref, mode, tag=""):
+    np.testing.assert_array_equal(gpu["score"], ref["score"], err_msg=f"score {tag}")
+    if mode in ("end", "full"):
+        np.testing.assert_array_equal(gpu["end_q"], ref["end_q"], err_msg=f"end_q {tag}")
+        np.testing.assert_array_equal(gpu["end_t"], ref["end_t"], err_msg=f"end_t {tag}")
+    if mode == "full":
+        np.testing.assert_array_equal(gpu["start_q"], ref["start_q"], err_msg=f"start_q {tag}")
+        np.testing.assert_array_equal(gpu["start_t"], ref["start_t"], err_msg=f"start_t {tag}")
+        for k, (a, b) in enumerate(zip(gpu["aln"], ref["aln"])):
+            assert a.tolist() == b.tolist(), f"alignment {k} {tag}"
+
+
+def run_both(capi, query, res, off, matrix, go, ge, mode, algo, **kw):
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        gpu = db.search(query, matrix, go, ge, mode, algo, **kw)
+    finally:
+        db.close()
+    start = kw.get("start", 0)
+    end = kw.get("end", len(off) - 1)
+    end = min(end if end is not None else len(off) - 1, len(off) - 1)
+    sub_off = off[start:end + 1] - off[start]
+    sub_res = res[off[start]:off[end]]
+    ref = _oracle.search(query, sub_res, sub_off, matrix, go, ge, mode, algo)
+    return gpu, ref
+
+
+# ---- the reference's own known-answer vectors through the C ABI -------------
+with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
+    VECTORS = json.load(f)["vectors"]
+
+
+@pytest.mark.parametrize("vec", VECTORS, ids=[v["id"] for v in VECTORS])
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_reference_vectors(capi, vec, mode):
+    m = np.array(ScoringMatrix.from_name(vec["matrix"]).int_array(), dtype=np.int32)
+    q = _oracle.encode(vec["query"])
+    res, off = _oracle.flatten([_oracle.encode(t) for t in vec["targets"]])
+    gpu, ref = run_both(capi, q, res, off, m, vec["gap_open"], vec["gap_extend"], mode, vec["algorithm"])
+    compare(gpu, ref, mode, vec["id"])
+    for k, want in enumerate(vec["score"]):
+        if want is not None:
+            assert int(gpu["score"][k]) == want
+    if mode == "full" and "cigar" in vec:
+        assert gpu["aln"][0].tolist() == [2, 0, 0, 0, 3, 0, 2, 0]
+
+
+def test_readme_example(capi):
+    # BASELINE.json configs[0]: README query vs its 4 targets, BLOSUM50, SW score
+    q = _oracle.encode(_data.README_QUERY)
+    res, off = _oracle.flatten([_oracle.encode(t) for t in _data.README_TARGETS])
+    for mode in ("score", "end", "full"):
+        gpu, ref = run_both(capi, q, res, off, B50, 3, 1, mode, "sw")
+        compare(gpu, ref, mode, "readme")
+
+
+# ---- seeded random databases --------------------------------------------------
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_random_small(capi, algo, mode):
+    rng = np.random.default_rng(11)
+    lengths = rng.integers(1, 400, size=300)
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, 53)
+    gpu, ref = run_both(capi, q, res, off, B62, 3, 1, mode, algo)
+    compare(gpu, ref, mode, f"{algo}/{mode}")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_related_sequences_with_ties(capi, algo):
+    # noisy copies of the query give long alignments, many equal-scoring cells
+    rng = np.random.default_rng(5)
+    q = _data.random_protein(rng, 120)
+    seqs = [_data.mutate(rng, q, rate) for rate in np.linspace(0.0, 0.6, 60)]
+    seqs += [np.concatenate([_data.random_protein(rng, 30), s, _data.random_protein(rng, 17)]) for s in seqs[:20]]
+    res, off = _oracle.flatten(seqs)
+    for go, ge in ((3, 1), (11, 1), (2, 2), (0, 0), (5, 0)):
+        gpu, ref = run_both(capi, q, res, off, B62, go, ge, "full", algo)
+        compare(gpu, ref, "full", f"{algo} gaps {go}/{ge}")
+
+
+@pytest.mark.parametrize("qlen", [1, 7, 8, 9, 53, 63, 64, 65, 100, 128, 129, 200, 333])
+def test_query_lengths_sw_score(capi, qlen):
+    # strip boundaries of the inter-sequence kernel (8-row blocks, 64-row strips)
+    rng = np.random.default_rng(qlen)
+    lengths = rng.integers(1, 300, size=400)
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, qlen)
+    gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "score", "sw")
+    compare(gpu, ref, "score", f"Q={qlen}")
+
+
+def test_edge_cases(capi):
+    rng = np.random.default_rng(2)
+    seqs = [np.zeros(0, dtype=np.uint8), _data.random_protein(rng, 1), _data.random_protein(rng, 2),
+            np.zeros(0, dtype=np.uint8), _data.random_protein(rng, 5),
+            _oracle.encode("WWWWWWWW"), _oracle.encode("X*BZX*BZ")]
+    res, off = _oracle.flatten(seqs)
+    for q in (_oracle.encode("W"), _oracle.encode("ACDWWWWWWY"), _data.random_protein(rng, 70)):
+        for algo in ALGOS:
+            for mode in ("score", "end", "full"):
+                gpu, ref = run_both(capi, q, res, off, B62, 3, 1, mode, algo)
+                compare(gpu, ref, mode, f"edge {algo}/{mode}/Q={len(q)}")
+
+
+def test_slices(capi):
+    rng = np.random.default_rng(9)
+    res, off = _data.random_db(rng, rng.integers(5, 200, size=257))
+    q = _data.random_protein(rng, 40)
+    for start, end in ((0, 257), (0, 1), (5, 5), (10, 139), (128, 257), (200, 10_000)):
+        for mode in ("score", "full"):
+            gpu, ref = run_both(capi, q, res, off, B62, 3, 1, mode, "sw", start=start, end=end)
+            compare(gpu, ref, mode, f"slice {start}:{end}")
+
+
+def test_sw_int16_saturation(capi):
+    # identical long sequences: SW score = sum of diagonal scores >> 32767,
+    # forcing the 16 -> 32 bit recompute for some targets only
+    rng = np.random.default_rng(4)
+    q = _data.random_protein(rng, 7000)
+    seqs = [q.copy(), _data.mutate(rng, q, 0.05), _data.random_protein(rng, 6000), q[:5000].copy(),
+            _data.random_protein(rng, 300), q[1000:6000].copy()]
+    seqs += [_data.random_protein(rng, int(n)) for n in rng.integers(10, 500, size=200)]
+    res, off = _oracle.flatten(seqs)
+    gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "score", "sw")
+    assert ref["score"].max() > 32767
+    compare(gpu, ref, "score", "saturation")
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_long_targets_overflow_ladder(capi, algo):
+    # shape of src/pyopal/tests/test_aligner.py:24-37 (lengths 1000..35000,
+    # query = the 1000-aa one); the reference asserts no values, the oracle does.
+    # Sub-sampled to keep the scalar checker to a few seconds.
+    rng = np.random.default_rng(0)
+    lengths = [1000, 2000, 9000, 17000, 35000]
+    seqs = [_data.random_protein(rng, n) for n in lengths]
+    res, off = _oracle.flatten(seqs)
+    gpu, ref = run_both(capi, seqs[0], res, off, B50, 3, 1, "score", algo)
+    compare(gpu, ref, "score", algo)
+    if algo == "nw":
+        assert ref["score"].min() < -32768  # really leaves the 16-bit range
+
+
+def test_opal_search_database_entry(capi):
+    """The literal opal.h entry point (host pointers in, result structs out)."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 120, size=37)]
+    q = _data.random_protein(rng, 31)
+    res, off = _oracle.flatten(seqs)
+    for mode, algo in (("score", "sw"), ("end", "hw"), ("full", "ov"), ("full", "nw")):
+        ref = _oracle.search(q, res, off, B62, 3, 1, mode, algo)
+        n = len(seqs)
+        results = (capi.OpalSearchResult * n)()
+        rptr = (ctypes.POINTER(capi.OpalSearchResult) * n)()
+        for k in range(n):
+            capi.lib().opalInitSearchResult(ctypes.byref(results[k]))
+            rptr[k] = ctypes.pointer(results[k])
+        seq_ptrs = (ctypes.c_void_p * n)(*[s.ctypes.data for s in seqs])
+        lens = np.array([len(s) for s in seqs], dtype=np.int32)
+        rc = capi.lib().opalSearchDatabase(
+            q.ctypes.data, len(q), ctypes.cast(seq_ptrs, ctypes.c_void_p), n, lens.ctypes.data, 3, 1,
+            B62.ctypes.data, 24, ctypes.cast(rptr, ctypes.c_void_p), capi.SEARCH[mode], capi.MODE[algo], 1)
+        assert rc == 0, capi.last_error()
+        for k in range(n):
+            r = results[k]
+            assert r.scoreSet and r.score == ref["score"][k]
+            if mode != "score":
+                assert (r.endLocationQuery, r.endLocationTarget) == (ref["end_q"][k], ref["end_t"][k])
+            if mode == "full":
+                assert (r.startLocationQuery, r.startLocationTarget) == (ref["start_q"][k], ref["start_t"][k])
+                assert [r.alignment[i] for i in range(r.alignmentLength)] == ref["aln"][k].tolist()
+
+
+def test_device_scores_entry(capi):
+    """Results left in HBM (miopalSearchDeviceScores), torch only as the allocator."""
+    import torch
+    rng = np.random.default_rng(21)
+    res, off = _data.random_db(rng, rng.integers(1, 350, size=1000))
+    q = _oracle.encode(_data.README_QUERY)
+    db = capi.DeviceDatabase(res, off, 24)
+    out = torch.full((1000,), -7, dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for algo in ALGOS:
+        db.search_device_scores(q, B62, out.data_ptr(), stream, 3, 1, algo)
+        torch.cuda.synchronize()
+        ref = _oracle.search(q, res, off, B62, 3, 1, "score", algo)
+        np.testing.assert_array_equal(out.cpu().numpy(), ref["score"], err_msg=algo)
+    db.close()
+
+
+def test_errors(capi):
+    rng = np.random.default_rng(1)
+    res, off = _data.random_db(rng, [10, 20])
+    db = capi.DeviceDatabase(res, off, 24)
+    q = _data.random_protein(rng, 5)
+    with pytest.raises(RuntimeError, match="code=3"):
+        capi.raise_for(capi.lib().miopalSearch(db.handle, q.ctypes.data, 5, 3, 1, B62.ctypes.data, 24, 0, 9,
+                                               0, 2, q.ctypes.data, None, None, None, None, None, None))
+    with pytest.raises(RuntimeError, match="alphabet"):
+        db.alphabet_length = 20
+        db.search(q, B62[:400], 3, 1, "score", "sw")
+    db.alphabet_length = 24
+    big = (B62.astype(np.int64) * 0 + 2 ** 28).astype(np.int32)
+    with pytest.raises(OverflowError):
+        db.search(q, big, 3, 1, "score", "nw")
+    db.close()
