@@ -50,6 +50,31 @@ EXPORTS = [
 ]
 
 
+def _share_hip_runtime() -> None:
+    """Make libmiopal.so and PyTorch-ROCm use ONE HIP runtime.
+
+    PyTorch wheels bundle their own ``libamdhip64.so.7`` (torch/lib). A process
+    that loads the system copy first (as libmiopal.so's RUNPATH would) and
+    torch's copy second ends up with two runtimes, and the second one reports
+    "No HIP GPUs are available". Loading torch's copy first, when torch is
+    installed, lets libmiopal.so bind to it by SONAME; torch itself is not
+    imported.
+    """
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> ctypes.CDLL:
     """Load libmiopal.so (built in-tree by ``__graft_entry__.build()`` or
     ``make -C pyopal_amd/csrc``). Raises if it is missing."""
@@ -59,6 +84,7 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()')")
+        _share_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         c_int, c_i64, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
         L.miopalDeviceCount.restype = c_int

@@ -162,7 +162,7 @@ def test_long_targets_overflow_ladder(capi, algo):
     # query = the 1000-aa one); the reference asserts no values, the oracle does.
     # Sub-sampled to keep the scalar checker to a few seconds.
     rng = np.random.default_rng(0)
-    lengths = [1000, 2000, 9000, 17000, 35000]
+    lengths = [1000, 2000, 9000, 17000, 35000, 45000]
     seqs = [_data.random_protein(rng, n) for n in lengths]
     res, off = _oracle.flatten(seqs)
     gpu, ref = run_both(capi, seqs[0], res, off, B50, 3, 1, "score", algo)
