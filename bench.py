@@ -143,7 +143,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic(),
+                "traffic_source": "profiles/r01_pmc_interseq_sw_score.json (separate rocprofv3 --pmc passes "
+                                  "FETCH_SIZE x2 + WRITE_SIZE, same kernel and workload)",
                 "kernel": "interseq_sw_score<56,false>",
                 "kernel_ms": round(k_ms, 4),
                 "kernel_gcups": round(float(Q) * N * L / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
@@ -160,6 +162,17 @@ def main():
     db.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (counters cannot be collected from inside the timed run)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_interseq_sw_score.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(query, residues, offsets, matrix, Q, N, L, gpu_scores):
