@@ -1,0 +1,726 @@
+"""Host-side mirror of ``pyopal.lib`` for the MI355X search path.
+
+Same names, argument meaning and error behaviour as the reference's Cython
+module (``src/pyopal/lib.pyx``); the computation behind `Aligner.align` is the
+HIP path reached through the C ABI (``pyopal_amd._capi``), never a CPU
+fallback. Per-residue loops of the reference (encoding, result fill) are
+numpy table look-ups / bulk array reads here.
+"""
+
+from __future__ import annotations
+
+import array
+import threading
+import typing
+
+import numpy as np
+
+from . import _capi
+from .matrices import ScoringMatrix
+
+__version__ = "0.1.0"
+
+MAX_ALPHABET_SIZE = 32  # src/pyopal/lib.pxd:28-32
+UINT32_MAX = 0xFFFFFFFF
+
+_OPAL_SEARCH_MODES = dict(_capi.SEARCH)        # src/pyopal/lib.pyx:73-77
+_OPAL_OVERFLOW_MODES = dict(_capi.OVERFLOW)    # src/pyopal/lib.pyx:85-88
+_OPAL_ALGORITHMS = dict(_capi.MODE)            # src/pyopal/lib.pyx:90-95
+_OPAL_ALIGNMENT_OPERATION = {"M": 0, "D": 1, "I": 2, "X": 3}  # src/pyopal/lib.pyx:97-102
+
+
+# --- Read/write lock ------------------------------------------------------------
+
+class SharedMutex:
+    """Readers-writer lock with the surface of ``src/pyopal/lib.pyx:153-181``
+    (``lock.read`` / ``lock.write`` context managers). Searches hold the read
+    side while the C call runs without the GIL; mutators hold the write side."""
+
+    def __init__(self):
+        self._cond = threading.Condition(threading.Lock())
+        self._readers = 0
+        self._writer = False
+        self.read = ReadLock(self)
+        self.write = WriteLock(self)
+
+
+class ReadLock:
+    def __init__(self, owner: SharedMutex):
+        self.owner = owner
+
+    def __enter__(self):
+        o = self.owner
+        with o._cond:
+            while o._writer:
+                o._cond.wait()
+            o._readers += 1
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        o = self.owner
+        with o._cond:
+            o._readers -= 1
+            if o._readers == 0:
+                o._cond.notify_all()
+
+
+class WriteLock:
+    def __init__(self, owner: SharedMutex):
+        self.owner = owner
+
+    def __enter__(self):
+        o = self.owner
+        with o._cond:
+            while o._writer or o._readers:
+                o._cond.wait()
+            o._writer = True
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        o = self.owner
+        with o._cond:
+            o._writer = False
+            o._cond.notify_all()
+
+
+# --- Alphabet -------------------------------------------------------------------
+
+class Alphabet:
+    """Ordinal encoding of sequences (``src/pyopal/lib.pyx:186-332``).
+
+    Letters outside the alphabet (lower case included: there is no case
+    folding) map to the index of ``*``; non-letters are rejected.
+    """
+
+    _DEFAULT_LETTERS = "ARNDCQEGHILKMFPSTWYVBZX*"
+    __slots__ = ("letters", "length", "_unknown", "_table", "_letters")
+
+    def __init__(self, letters: str = _DEFAULT_LETTERS):
+        if not isinstance(letters, str):
+            raise TypeError(f"expected str, found {type(letters).__name__}")
+        if len(letters) != len(set(letters)):
+            raise ValueError("duplicate symbols in alphabet letters")
+        if any(x != "*" and not x.isupper() for x in letters):
+            raise ValueError("alphabet must only contain uppercase characters or wildcard")
+        if len(letters) > MAX_ALPHABET_SIZE:
+            raise ValueError("Cannot use alphabet of more than 32 symbols")
+        self.letters = letters
+        self.length = len(letters)
+        self._unknown = letters.find("*")
+        self._letters = np.frombuffer(letters.encode("ascii"), dtype=np.uint8).copy()
+        # -2: not a letter; -1: letter without a code (alphabet has no wildcard)
+        table = np.full(256, -2, dtype=np.int16)
+        for c in range(256):
+            if (65 <= c <= 90) or (97 <= c <= 122):
+                table[c] = self._unknown
+        for i, x in enumerate(self._letters):
+            if (65 <= x <= 90) or (97 <= x <= 122):
+                table[x] = i
+        self._table = table
+
+    def __len__(self):
+        return self.length
+
+    def __contains__(self, item):
+        return item in self.letters
+
+    def __getitem__(self, index: int):
+        index_ = index
+        if index_ < 0:
+            index_ += self.length
+        if index_ < 0 or index_ >= self.length:
+            raise IndexError(index)
+        return self.letters[index_]
+
+    def __reduce__(self):
+        return type(self), (self.letters,)
+
+    def __repr__(self):
+        if self.letters == self._DEFAULT_LETTERS:
+            return f"{type(self).__name__}()"
+        return f"{type(self).__name__}({self.letters!r})"
+
+    def __str__(self):
+        return self.letters
+
+    def __eq__(self, item):
+        if isinstance(item, str):
+            return self.letters == item
+        if isinstance(item, Alphabet):
+            return self.letters == item.letters
+        return False
+
+    def __hash__(self):
+        return hash(self.letters)
+
+    # -- bulk forms used by Database --------------------------------------------
+    def _encode_array(self, sequence) -> np.ndarray:
+        if isinstance(sequence, str):
+            sequence = sequence.encode("ascii")
+        raw = np.frombuffer(memoryview(sequence).cast("B"), dtype=np.uint8)
+        codes = self._table[raw]
+        if codes.size and codes.min() < 0:
+            pos = int(np.argmax(codes < 0))
+            letter = int(raw[pos])
+            if codes[pos] == -2:
+                raise ValueError(f"character outside ASCII range: {letter!r}")
+            raise ValueError(f"non-alphabet character in sequence: {chr(letter)!r}")
+        return codes.astype(np.uint8)
+
+    def encode_into(self, sequence, encoded) -> None:
+        src = memoryview(sequence).cast("B")
+        dst = memoryview(encoded).cast("B")
+        if len(src) != len(dst):
+            raise ValueError("Buffers do not have the same dimensions")
+        dst[:] = self._encode_array(src).tobytes()
+
+    def decode_into(self, encoded, sequence) -> None:
+        src = np.frombuffer(memoryview(encoded).cast("B"), dtype=np.uint8)
+        dst = memoryview(sequence).cast("B")
+        if len(src) != len(dst):
+            raise ValueError("Buffers do not have the same dimensions")
+        if src.size and src.max() >= self.length:
+            code = int(src[np.argmax(src >= self.length)])
+            raise ValueError(f"invalid index in encoded sequence: {code!r}")
+        dst[:] = self._letters[src].tobytes()
+
+    def encode(self, sequence) -> bytes:
+        return self._encode_array(sequence).tobytes()
+
+    def decode(self, encoded) -> str:
+        decoded = bytearray(len(encoded))
+        self.decode_into(encoded, decoded)
+        return decoded.decode("ascii")
+
+
+# --- Sequence storage -------------------------------------------------------------
+
+class BaseDatabase:
+    """Base class of sequence databases (``src/pyopal/lib.pyx:337-466``).
+
+    The reference's three C-level accessors (``get_sequences``/``get_lengths``/
+    ``get_size``, ``src/pyopal/lib.pxd:90-92``) become `_get_size`,
+    `_get_lengths` and `_get_encoded`; a subclass that implements them can be
+    searched by `Aligner.align`.
+    """
+
+    _DEFAULT_ALPHABET = Alphabet()
+
+    def __init__(self, sequences=(), alphabet=None):
+        self.lock = SharedMutex()
+        self._mirrors: typing.Dict[int, typing.Tuple[int, _capi.DeviceDatabase]] = {}
+        self._mirror_guard = threading.Lock()
+        self._version = 0
+        if alphabet is None:
+            self.alphabet = self._DEFAULT_ALPHABET
+        elif isinstance(alphabet, Alphabet):
+            self.alphabet = alphabet
+        else:
+            self.alphabet = Alphabet(alphabet)
+        if sequences:
+            raise TypeError("cannot create a `BaseDatabase` with sequences")
+
+    # -- interface to implement ---------------------------------------------------
+    def _get_size(self) -> int:
+        return 0
+
+    def _get_lengths(self) -> typing.Sequence[int]:
+        raise NotImplementedError("BaseDatabase.get_lengths")
+
+    def _get_encoded(self) -> typing.Sequence[bytes]:
+        raise NotImplementedError("BaseDatabase.get_sequences")
+
+    # -- device mirror -----------------------------------
+    def _device_mirror(self, device: int = 0) -> _capi.DeviceDatabase:
+        """Packed copy of the database in HBM, rebuilt only after a mutation.
+        Called with the read lock held."""
+        with self._mirror_guard:
+            entry = self._mirrors.get(device)
+            if entry is not None and entry[0] == self._version:
+                return entry[1]
+            if entry is not None:
+                entry[1].close()
+            seqs = self._get_encoded()
+            lengths = np.fromiter(self._get_lengths(), dtype=np.int64, count=len(seqs))
+            offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
+            np.cumsum(lengths, out=offsets[1:])
+            residues = np.frombuffer(b"".join(seqs), dtype=np.uint8)
+            mirror = _capi.DeviceDatabase(residues, offsets, self.alphabet.length, device)
+            self._mirrors[device] = (self._version, mirror)
+            return mirror
+
+    def _invalidate(self) -> None:
+        """Called with the write lock held by every mutator."""
+        self._version += 1
+
+    # -- properties -----------------------------------------------------------------
+    @property
+    def lengths(self) -> typing.List[int]:
+        with self.lock.read:
+            return [int(x) for x in self._get_lengths()][: self._get_size()]
+
+    @property
+    def total_length(self) -> int:
+        with self.lock.read:
+            if self._get_size() == 0:
+                return 0
+            return int(sum(self._get_lengths()))
+
+    # -- sequence interface ---------------------------------------------------------
+    def __contains__(self, query):
+        encoded = self.alphabet.encode(query)
+        with self.lock.read:
+            if self._get_size() == 0:
+                return False
+            return any(s == encoded for s in self._get_encoded())
+
+    def __len__(self):
+        with self.lock.read:
+            return self._get_size()
+
+    def __getitem__(self, index: int):
+        with self.lock.read:
+            size = self._get_size()
+            index_ = index
+            if index_ < 0:
+                index_ += size
+            if index_ < 0 or index_ >= size:
+                raise IndexError(index)
+            return self.alphabet.decode(self._get_encoded()[index_])
+
+
+class Database(BaseDatabase):
+    """A database of target sequences, stored encoded
+    (``src/pyopal/lib.pyx:469-778``)."""
+
+    def __init__(self, sequences=(), alphabet=None):
+        super().__init__(alphabet=alphabet)
+        self._sequences: typing.List[bytes] = []
+        self._lengths: typing.List[int] = []
+        self.clear()
+        self.extend(sequences)
+
+    def __reduce__(self):
+        return (type(self), ((), self.alphabet), None, iter(self))
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    # -- database interface -----------------------------------------------------------
+    def _get_size(self) -> int:
+        return len(self._sequences)
+
+    def _get_lengths(self):
+        return self._lengths
+
+    def _get_encoded(self):
+        return self._sequences
+
+    def _encode(self, sequence) -> bytes:
+        return self.alphabet.encode(sequence)
+
+    # -- sequence interface -----------------------------------------------------------
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return self.extract(range(*index.indices(len(self))))
+        return super().__getitem__(index)
+
+    def __setitem__(self, index: int, sequence):
+        encoded = self._encode(sequence)
+        with self.lock.write:
+            size = len(self._sequences)
+            index_ = index
+            if index_ < 0:
+                index_ += size
+            if index_ < 0 or index_ >= size:
+                raise IndexError(index)
+            self._sequences[index_] = encoded
+            self._lengths[index_] = len(encoded)
+            self._invalidate()
+
+    def __delitem__(self, index: int):
+        with self.lock.write:
+            size = len(self._sequences)
+            index_ = index
+            if index_ < 0:
+                index_ += size
+            if index_ < 0 or index_ >= size:
+                raise IndexError(index)
+            del self._sequences[index_]
+            del self._lengths[index_]
+            self._invalidate()
+
+    def clear(self) -> None:
+        with self.lock.write:
+            self._sequences.clear()
+            self._lengths.clear()
+            self._invalidate()
+
+    def extend(self, sequences) -> None:
+        for sequence in sequences:
+            self.append(sequence)
+
+    def append(self, sequence) -> None:
+        encoded = self._encode(sequence)
+        with self.lock.write:
+            self._sequences.append(encoded)
+            self._lengths.append(len(encoded))
+            self._invalidate()
+
+    def reverse(self) -> None:
+        with self.lock.write:
+            self._sequences.reverse()
+            self._lengths.reverse()
+            self._invalidate()
+
+    def insert(self, index: int, sequence) -> None:
+        encoded = self._encode(sequence)
+        with self.lock.write:
+            size = len(self._sequences)
+            index_ = index
+            if index_ < 0:
+                index_ += size
+            if index_ < 0:
+                index_ = 0
+            elif index_ >= size:
+                index_ = size
+            self._sequences.insert(index_, encoded)
+            self._lengths.insert(index_, len(encoded))
+            self._invalidate()
+
+    # -- subsets (share the encoded buffers, like the reference's shared_ptr) ------------
+    def _subset(self) -> "Database":
+        subdb = Database.__new__(Database)
+        BaseDatabase.__init__(subdb, alphabet=self.alphabet)
+        subdb._sequences = []
+        subdb._lengths = []
+        return subdb
+
+    def mask(self, bitmask) -> "Database":
+        subdb = self._subset()
+        with self.lock.read:
+            size = self._get_size()
+            i = 0
+            for b in bitmask:
+                if i >= size:
+                    raise IndexError(bitmask)
+                if b:
+                    subdb._sequences.append(self._sequences[i])
+                    subdb._lengths.append(self._lengths[i])
+                i += 1
+            if i < size:
+                raise IndexError(bitmask)
+        return subdb
+
+    def extract(self, indices) -> "Database":
+        subdb = self._subset()
+        with self.lock.read:
+            size = self._get_size()
+            for index in indices:
+                if index < 0 or index >= size:
+                    raise IndexError(index)
+                subdb._sequences.append(self._sequences[index])
+                subdb._lengths.append(self._lengths[index])
+        return subdb
+
+
+# --- Results ----------------------------------------------------------------------
+
+class ScoreResult:
+    """Result of a search in ``score`` mode (``src/pyopal/lib.pyx:783-834``)."""
+
+    __slots__ = ("_target_index", "_score", "_score_set", "_query_end", "_target_end",
+                 "_query_start", "_target_start", "_ops", "_query_length", "_target_length")
+
+    def __new__(cls, *args, **kwargs):
+        self = object.__new__(cls)
+        self._target_index = -1
+        self._score = 0
+        self._score_set = False
+        self._query_end = self._target_end = -1
+        self._query_start = self._target_start = -1
+        self._ops = None
+        self._query_length = self._target_length = -1
+        return self
+
+    def __init__(self, target_index: int, score: int):
+        if target_index < 0:
+            raise OverflowError("can't convert negative value to size_t")
+        self._target_index = target_index
+        self._score = score
+        self._score_set = True
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.target_index}, score={self.score!r})"
+
+    def __reduce__(self):
+        return type(self), (self.target_index, self.score)
+
+    def __eq__(self, other):
+        if not isinstance(other, ScoreResult):
+            return NotImplemented
+        return self.__reduce__()[1] == other.__reduce__()[1]
+
+    __hash__ = None
+
+    @property
+    def target_index(self) -> int:
+        assert self._target_index >= 0
+        return self._target_index
+
+    @property
+    def score(self) -> int:
+        assert self._score_set
+        return self._score
+
+
+class EndResult(ScoreResult):
+    """Result of a search in ``end`` mode (``src/pyopal/lib.pyx:837-881``)."""
+
+    __slots__ = ()
+
+    def __init__(self, target_index: int, score: int, query_end: int, target_end: int):
+        super().__init__(target_index, score)
+        self._query_end = query_end
+        self._target_end = target_end
+
+    def __repr__(self):
+        return (f"{type(self).__name__}({self.target_index}, score={self.score!r}, "
+                f"query_end={self.query_end!r}, target_end={self.target_end!r})")
+
+    def __reduce__(self):
+        return type(self), (self.target_index, self.score, self.query_end, self.target_end)
+
+    @property
+    def query_end(self) -> int:
+        assert self._query_end >= 0
+        return self._query_end
+
+    @property
+    def target_end(self) -> int:
+        assert self._target_end >= 0
+        return self._target_end
+
+
+_OPS_TO_TEXT = bytes.maketrans(bytes([0, 1, 2, 3]), b"MDIX")  # src/pyopal/lib.pyx:991
+
+
+class FullResult(EndResult):
+    """Result of a search in ``full`` mode (``src/pyopal/lib.pyx:884-1119``)."""
+
+    __slots__ = ()
+
+    def __init__(self, target_index: int, score: int, query_end: int, target_end: int,
+                 query_start: int, target_start: int, query_length: int, target_length: int,
+                 alignment: str):
+        if alignment is None:
+            raise TypeError("Argument 'alignment' must not be None")
+        super().__init__(target_index, score, query_end, target_end)
+        self._query_length = query_length
+        self._target_length = target_length
+        self._query_start = query_start
+        self._target_start = target_start
+        self._ops = bytes(_OPAL_ALIGNMENT_OPERATION[x] for x in alignment)
+
+    def __repr__(self):
+        return (f"{type(self).__name__}({self.target_index}, score={self.score!r}, "
+                f"query_end={self.query_end!r}, target_end={self.target_end!r}, "
+                f"query_start={self.query_start!r}, target_start={self.target_start!r}, "
+                f"query_length={self.query_length!r}, target_length={self.target_length!r}, "
+                f"alignment={self.alignment!r})")
+
+    def __reduce__(self):
+        return (type(self), (self.target_index, self.score, self.query_end, self.target_end,
+                             self.query_start, self.target_start, self.query_length,
+                             self.target_length, self.alignment))
+
+    @property
+    def query_start(self) -> int:
+        assert self._query_start >= 0
+        return self._query_start
+
+    @property
+    def target_start(self) -> int:
+        assert self._target_start >= 0
+        return self._target_start
+
+    @property
+    def query_length(self) -> int:
+        assert self._query_length >= 0
+        return self._query_length
+
+    @property
+    def target_length(self) -> int:
+        assert self._target_length >= 0
+        return self._target_length
+
+    @property
+    def alignment(self) -> str:
+        """Operations as a string over ``MDIX`` (D: query residue against a gap,
+        I: target residue against a gap)."""
+        return (self._ops or b"").translate(_OPS_TO_TEXT).decode("ascii")
+
+    def cigar(self) -> typing.Optional[str]:
+        """CIGAR string in SAM convention (``op % 3`` -> ``M, I, D``)."""
+        ops = self._ops
+        if not ops:
+            return None
+        symbols = "MID"
+        chunks = []
+        count = 0
+        current = ops[0] % 3
+        for op in ops:
+            symbol = op % 3
+            if symbol == current:
+                count += 1
+            else:
+                chunks.append(f"{count}{symbols[current]}")
+                current = symbol
+                count = 1
+        chunks.append(f"{count}{symbols[current]}")
+        return "".join(chunks)
+
+    def identity(self) -> float:
+        assert self._ops is not None
+        matches = np.float32(self._ops.count(0))
+        mismatches = self._ops.count(3)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return float(matches / np.float32(matches + mismatches))
+
+    def coverage(self, reference: str = "query") -> float:
+        assert self._ops is not None
+        if reference == "query":
+            reflength = self._query_length
+            length = self._query_end + 1 - self._query_start
+            operation = 1
+        elif reference == "target":
+            reflength = self._target_length
+            length = self._target_end + 1 - self._target_start
+            operation = 2
+        else:
+            raise ValueError(f"Invalid coverage reference: {reference!r}")
+        # edge operations that are gaps in the reference do not cover it
+        for op in self._ops:
+            if op != operation:
+                break
+            length -= 1
+        for op in reversed(self._ops):
+            if op != operation:
+                break
+            length -= 1
+        return 0.0 if length < 0 else float(np.float32(length) / np.float32(reflength))
+
+
+_RESULT_TYPES = {"score": ScoreResult, "end": EndResult, "full": FullResult}
+
+
+# --- Aligner ------------------------------------------------------------------------
+
+class Aligner:
+    """The Opal aligner, served by MI355X kernels
+    (``src/pyopal/lib.pyx:1122-1383``)."""
+
+    _DEFAULT_SCORING_MATRIX = ScoringMatrix.from_name("BLOSUM50")
+    _DEFAULT_GAP_OPEN = 3
+    _DEFAULT_GAP_EXTEND = 1
+
+    def __init__(self, scoring_matrix=None, gap_open: int = _DEFAULT_GAP_OPEN,
+                 gap_extend: int = _DEFAULT_GAP_EXTEND):
+        if scoring_matrix is None:
+            self.scoring_matrix = self._DEFAULT_SCORING_MATRIX
+        elif isinstance(scoring_matrix, str):
+            self.scoring_matrix = ScoringMatrix.from_name(scoring_matrix)
+        elif isinstance(scoring_matrix, ScoringMatrix):
+            self.scoring_matrix = scoring_matrix
+        else:
+            ty = type(scoring_matrix).__name__
+            raise TypeError(f"expected str or ScoringMatrix, found {ty}")
+        self.alphabet = Alphabet(self.scoring_matrix.alphabet)
+        self.gap_open = int(gap_open)
+        self.gap_extend = int(gap_extend)
+
+        # the one backend: HIP kernels behind libmiopal.so (the slot where the
+        # reference picks SSE2/SSE4/AVX2/NEON, src/pyopal/lib.pyx:1213-1227)
+        try:
+            _capi.lib()
+        except (RuntimeError, OSError) as err:
+            raise RuntimeError("no supported SIMD backend available") from err
+        from .platform.hip import searchHIP
+        self._search = searchHIP
+
+        if not self.scoring_matrix.is_integer():
+            raise ValueError("Integer scoring matrix is expected")
+        self._int_matrix = self.scoring_matrix.int_array()
+
+    def __repr__(self):
+        args = []
+        if self.scoring_matrix != self._DEFAULT_SCORING_MATRIX:
+            args.append(f"{self.scoring_matrix!r}")
+        if self.gap_open != self._DEFAULT_GAP_OPEN:
+            args.append(f"gap_open={self.gap_open!r}")
+        if self.gap_extend != self._DEFAULT_GAP_EXTEND:
+            args.append(f"gap_extend={self.gap_extend!r}")
+        return f"{type(self).__name__}({', '.join(args)})"
+
+    def __reduce__(self):
+        return type(self), (self.scoring_matrix, self.gap_open, self.gap_extend)
+
+    def __eq__(self, other):
+        if not isinstance(other, Aligner):
+            return NotImplemented
+        return self.__reduce__()[1] == other.__reduce__()[1]
+
+    __hash__ = None
+
+    def align(self, query, database: BaseDatabase, *, mode: str = "score",
+              overflow: str = "buckets", algorithm: str = "sw", start: int = 0,
+              end: int = UINT32_MAX, device: int = 0) -> typing.List[ScoreResult]:
+        """Align the query to every target of ``database[start:end]``.
+
+        Same keywords as the reference (``src/pyopal/lib.pyx:1258-1268``);
+        ``device`` (extension) selects the GPU holding the database mirror.
+        ``overflow`` is validated and otherwise ignored: the GPU path picks the
+        narrowest exact lane width per target, results are identical.
+        """
+        if query is None:
+            raise TypeError("Argument 'query' must not be None")
+        if not isinstance(database, BaseDatabase):
+            raise TypeError(f"Argument 'database' has incorrect type (expected BaseDatabase, "
+                            f"got {type(database).__name__})")
+        if mode in _OPAL_SEARCH_MODES:
+            _mode = _OPAL_SEARCH_MODES[mode]
+        else:
+            raise ValueError(f"invalid search mode: {mode!r}")
+        if overflow in _OPAL_OVERFLOW_MODES:
+            _overflow = _OPAL_OVERFLOW_MODES[overflow]
+        else:
+            raise ValueError(f"invalid overflow mode: {overflow!r}")
+        if algorithm in _OPAL_ALGORITHMS:
+            _algo = _OPAL_ALGORITHMS[algorithm]
+        else:
+            raise ValueError(f"invalid algorithm: {algorithm!r}")
+        if start < 0 or end < 0:
+            raise OverflowError("can't convert negative value to uint32_t")
+
+        if database.alphabet != self.alphabet:
+            raise ValueError("database and score matrix have different alphabets")
+
+        encoded = database.alphabet.encode(query)
+
+        with database.lock.read:
+            size = database._get_size()
+            if end < start:
+                raise IndexError("database slice end is lower than start")
+            if end > size:
+                end = size
+            if start > size:
+                # the reference does not guard this case (unsigned underflow at
+                # src/pyopal/platform/pyx.in:62); an IndexError is raised instead
+                raise IndexError("database slice start is past the end of the database")
+            return self._search(encoded, database, _mode, _overflow, _algo, self.gap_open,
+                                self.gap_extend, self._int_matrix, start, end, device=device)
+
+
+def _int_matrix_array(matrix) -> np.ndarray:
+    if isinstance(matrix, array.array):
+        return np.frombuffer(matrix, dtype=np.int32)
+    return np.ascontiguousarray(matrix, dtype=np.int32)

@@ -1,0 +1,114 @@
+"""`Aligner.align` / `pyopal.align` on the GPU: the reference's own assertions
+(src/pyopal/tests/test_aligner.py:39-131, test_align.py:9-37, doctests) run
+against ``pyopal_amd`` unchanged in meaning."""
+import multiprocessing.pool
+import random
+import threading
+
+import numpy as np
+import pytest
+
+import _data
+import _oracle
+import pyopal_amd as pyopal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nw_test1():
+    # src/pyopal/tests/test_aligner.py:42-79
+    aligner, db = pyopal.Aligner(), pyopal.Database(["AACCGCTG"])
+    for kw in ({}, {"mode": "score"}):
+        r = aligner.align("ACCTCG", db, algorithm="nw", **kw)
+        assert len(r) == 1 and type(r[0]) is pyopal.ScoreResult and r[0].score == 44
+    r = aligner.align("ACCTCG", db, algorithm="nw", mode="end")
+    assert type(r[0]) is pyopal.EndResult and (r[0].score, r[0].query_end, r[0].target_end) == (44, 5, 7)
+    r = aligner.align("ACCTCG", db, algorithm="nw", mode="full")[0]
+    assert type(r) is pyopal.FullResult and r.alignment is not None
+    assert (r.score, r.query_start, r.query_end, r.target_start, r.target_end) == (44, 0, 5, 0, 7)
+    assert r.coverage("query") == 1 and r.coverage("target") == 7 / 8
+    assert r.cigar() == "1D5M1D1M"                      # doctest src/pyopal/lib.pyx:1006-1010
+    assert (r.query_length, r.target_length, r.target_index) == (6, 8, 0)
+
+
+def test_sw_test1():
+    # src/pyopal/tests/test_aligner.py:93-131
+    aligner, db = pyopal.Aligner(), pyopal.Database(["AACCGCTG"])
+    assert aligner.align("ACCTCG", db, algorithm="sw")[0].score == 47
+    r = aligner.align("ACCTCG", db, algorithm="sw", mode="end")[0]
+    assert (r.score, r.query_end, r.target_end) == (47, 5, 7)
+    r = aligner.align("ACCTCG", db, algorithm="sw", mode="full")[0]
+    assert (r.score, r.query_start, r.query_end, r.target_start, r.target_end) == (47, 0, 5, 1, 7)
+    assert r.coverage("query") == pytest.approx(1) and r.coverage("target") == pytest.approx(7 / 8)
+
+
+@pytest.mark.parametrize("algorithm", ["nw", "hw", "ov", "sw"])
+def test_overflow_does_not_raise(algorithm):
+    # src/pyopal/tests/test_aligner.py:24-37 (35 proteins of 1000..35000 aa); the
+    # reference checks only that no exception escapes; scores are checked against
+    # the oracle for a sub-sample in test_gpu_parity.py
+    rnd = random.Random(0)
+    proteins = ["".join(rnd.choices(_data.AA20, k=k)) for k in range(1000, 36000, 1000)]
+    results = pyopal.Aligner().align(proteins[0], pyopal.Database(proteins), mode="score", algorithm=algorithm)
+    assert len(results) == 35 and [r.target_index for r in results] == list(range(35))
+
+
+@pytest.mark.parametrize("threads", [1, 2, 3])
+def test_align_threads(threads):
+    # src/pyopal/tests/test_align.py:9-37
+    target = ["AACCGCTG", "AACCGCTA", "AACCGCTC", "AACCGCTT"]
+    results = list(pyopal.align("ACCTCG", target, threads=threads, mode="full", algorithm="nw", ordered=True))
+    assert [r.target_index for r in results] == [0, 1, 2, 3]
+    r = results[0]
+    assert (r.target_start, r.target_end, r.query_start, r.query_end, r.score) == (0, 7, 0, 5, 44)
+    assert [x.score for x in results] == [44, 36, 39, 34]   # oracle values for targets 1-3
+
+
+def test_align_doctest_and_pool():
+    # src/pyopal/_align.py:106-111
+    targets = ["AACCGCTG", "ATGCGCT", "TTATTACG"]
+    assert [r.score for r in pyopal.align("ACCTG", targets, gap_open=2, ordered=True)] == [41, 31, 23]
+    with multiprocessing.pool.ThreadPool(2) as pool:
+        unordered = list(pyopal.align("ACCTG", targets, gap_open=2, threads=2, pool=pool))
+    assert sorted((r.target_index, r.score) for r in unordered) == [(0, 41), (1, 31), (2, 23)]
+
+
+def test_slices_and_mirror_invalidation():
+    rng = np.random.default_rng(6)
+    seqs = ["".join(_data.AA20[i] for i in rng.integers(0, 20, size=int(n))) for n in rng.integers(5, 80, size=50)]
+    db = pyopal.Database(seqs)
+    aligner = pyopal.Aligner("BLOSUM62")
+    full = [r.score for r in aligner.align(seqs[3], db)]
+    part = aligner.align(seqs[3], db, start=10, end=20)
+    assert [r.target_index for r in part] == list(range(10, 20))
+    assert [r.score for r in part] == full[10:20]
+    assert [r.score for r in aligner.align(seqs[3], db, start=45, end=10_000)] == full[45:]
+    # mutators invalidate the device mirror (they hold the write lock)
+    db.append(seqs[3])
+    db.reverse()
+    again = [r.score for r in aligner.align(seqs[3], db)]
+    assert again == [full[3]] + full[::-1]
+    assert again[0] == max(again)
+    sub = db.extract([0, 5, 7])
+    assert [r.score for r in aligner.align(seqs[3], sub)] == [again[0], again[5], again[7]]
+
+
+def test_concurrent_queries_share_one_database():
+    # README.md:116-144: several threads query one Database through one Aligner
+    rng = np.random.default_rng(12)
+    res, off = _data.random_db(rng, rng.integers(10, 200, size=400))
+    seqs = [_oracle.NCBI and "".join(_oracle.NCBI[c] for c in res[off[k]:off[k + 1]]) for k in range(400)]
+    db, aligner = pyopal.Database(seqs), pyopal.Aligner("BLOSUM62")
+    queries = seqs[:8]
+    want = [[r.score for r in aligner.align(q, db)] for q in queries]
+    got = [None] * len(queries)
+
+    def work(i):
+        got[i] = [r.score for r in aligner.align(queries[i], db, mode="end")]
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(queries))]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert got == want
+    m = np.array(aligner.scoring_matrix.int_array(), dtype=np.int32)
+    ref = _oracle.search(_oracle.encode(queries[0]), res, off, m, 3, 1, "score", "sw")
+    assert want[0] == ref["score"].tolist()
