@@ -91,7 +91,7 @@ struct PackArgs {
 };
 
 // ---- launchers (defined next to their kernels) -----------------------------
-hipError_t launchInterseqSwScore(const InterseqArgs& a, int rowsPerStrip, hipStream_t stream);
+hipError_t launchInterseqSwScore(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);

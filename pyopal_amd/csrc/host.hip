@@ -59,6 +59,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 6ll << 30;  // bytes of direction workspace per traceback batch
 constexpr int64_t kInt32Safe = 1ll << 29;
+constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
 
 // ---------------------------------------------------------------------------
 // per-stream workspace: growable device buffers reused in stream order
@@ -142,6 +143,7 @@ struct MiopalDb {
     int alphabet = 0;
     int64_t count = 0;
     int64_t total = 0;
+    int64_t maxLen = 0;            // longest sequence (range checks)
     std::vector<int64_t> offsets;  // host copy, [count + 1]
     uint8_t* d_residues = nullptr;
     int64_t* d_offsets = nullptr;
@@ -335,6 +337,14 @@ struct Search {
     }
 
     int prepare() {
+        maxScore = *std::max_element(matrix, matrix + A * A);
+        minScore = *std::min_element(matrix, matrix + A * A);
+        return 0;
+    }
+
+    // query + matrix are only needed by the intra-sequence / traceback kernels
+    int ensurePairInputs() {
+        if (d_query) return 0;
         void* p;
         RC_TRY(ws->get(kQuery, (size_t)std::max(Q, 1), &p));
         d_query = (uint8_t*)p;
@@ -342,8 +352,6 @@ struct Search {
         d_matrix = (int32_t*)p;
         RC_TRY(upload(d_query, query, (size_t)Q, stream));
         RC_TRY(upload(d_matrix, (const int32_t*)matrix, (size_t)A * A, stream));
-        maxScore = *std::max_element(matrix, matrix + A * A);
-        minScore = *std::min_element(matrix, matrix + A * A);
         return 0;
     }
 
@@ -370,6 +378,7 @@ struct Search {
     int runPairs(std::vector<PairJob>& jobs, bool trace, int32_t* d_score, int32_t* d_endI,
                  int32_t* d_endJ, uint8_t* d_dirs) {
         if (jobs.empty()) return 0;
+        RC_TRY(ensurePairInputs());
         int64_t wsElems = 0;
         for (auto& j : jobs) {
             j.wsOff = wsElems;
@@ -414,13 +423,15 @@ struct Search {
 
     // Score pass (all search types). d_score/d_endI/d_endJ are in database order.
     int scorePass(int32_t* d_score, int32_t* d_endI, int32_t* d_endJ) {
+        return scorePassImpl(d_score, d_endI, d_endJ, true);
+    }
+
+    int scorePassImpl(int32_t* d_score, int32_t* d_endI, int32_t* d_endJ, bool useHalf) {
         DpRules r;
         RC_TRY(rulesFor(mode, &r));
         const int rules = packRules(r);
         std::vector<PairJob> jobs;
-        int64_t maxLen = 0;
-        for (int64_t k = start; k < end; ++k) maxLen = std::max<int64_t>(maxLen, dbLen(db, k));
-        RC_TRY(checkInt32(maxLen));
+        RC_TRY(checkInt32(db->maxLen));
 
         if (!interseqUsable()) {
             jobs.reserve((size_t)n);
@@ -437,17 +448,34 @@ struct Search {
             const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
             const int qPad = nStrips * rows;
             const int nSym = A + 1;
-            // query profile: profile[t][i] = S[q_i][t]; padding symbol and padding rows = -32768
-            std::vector<int16_t> prof((size_t)nSym * qPad, (int16_t)-32768);
+            // Lane arithmetic: packed half floats are exact for integers below 2048 and
+            // cost fewer instructions per cell (interseq.hip); saturating int16 is the
+            // second rung, the int32 intra-sequence kernel the last.
+            const bool halfFloat = useHalf && maxScore <= 1024 && minScore >= -1024;
+            // query profile: profile[t][i] = S[q_i][t]; padding symbol and padding rows can
+            // never win a max: -32768 (int16) or -inf (half)
+            auto enc = [&](int v) -> int16_t {
+                if (!halfFloat) return (int16_t)v;
+                const _Float16 h = (_Float16)(float)v;
+                int16_t bits;
+                memcpy(&bits, &h, sizeof bits);
+                return bits;
+            };
+            const int16_t padValue = halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
+            std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
-                for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = (int16_t)matrix[query[i] * A + t];
+                for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t]);
             void *pp, *vs, *vo, *ct;
             RC_TRY(ws->get(kProfile, prof.size() * sizeof(int16_t), &pp));
             RC_TRY(ws->get(kViewScore, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vs));
             RC_TRY(ws->get(kViewOvf, (size_t)view->nGroups * kGroupTargets, &vo));
             RC_TRY(ws->get(kCounter, sizeof(int32_t), &ct));
             RC_TRY(upload((int16_t*)pp, prof.data(), prof.size(), stream));
-            HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
+            // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
+            const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
+            const int64_t limit = halfFloat ? 2048 : 32767;
+            const bool mayOverflow = reach >= limit;
+            if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
             ia.pack = view->d_pack;
             ia.groupOff = view->d_groupOff;
@@ -477,7 +505,7 @@ struct Search {
                 HIP_TRY(hipEventCreate(&e1));
                 HIP_TRY(hipEventRecord(e0, stream));
             }
-            HIP_TRY(launchInterseqSwScore(ia, rows, stream));
+            HIP_TRY(launchInterseqSwScore(ia, rows, halfFloat, stream));
             if (timed) {
                 HIP_TRY(hipEventRecord(e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
@@ -485,13 +513,16 @@ struct Search {
                 db->lastTimed = ws;
             }
             HIP_TRY(launchScatter(ia.score, ia.overflow, view->d_ids, view->nPacked, start, d_score,
-                                  (int32_t*)ct, stream));
-            // 16-bit lanes can only saturate when min(Q, L) * maxScore reaches 32767
-            const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
-            if (reach >= 32767) {
+                                  mayOverflow ? (int32_t*)ct : nullptr, stream));
+            if (mayOverflow) {
                 int32_t count = 0;
                 RC_TRY(download(&count, (const int32_t*)ct, 1, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
+                if (halfFloat && count > kMaxDirectRecompute) {
+                    // many targets left the half-float range: second rung, int16 lanes,
+                    // over the whole view (its results overwrite the first pass)
+                    return scorePassImpl(d_score, d_endI, d_endJ, false);
+                }
                 if (count > 0) {
                     std::vector<uint8_t> flags((size_t)view->nPacked);
                     RC_TRY(download(flags.data(), (const uint8_t*)vo, flags.size(), stream));
@@ -533,6 +564,7 @@ int createCommon(MiopalDb** out, const unsigned char* residues, const std::vecto
     db->count = count;
     db->offsets = offsets;
     db->total = offsets[(size_t)count];
+    for (int64_t k = 0; k < count; ++k) db->maxLen = std::max(db->maxLen, offsets[(size_t)k + 1] - offsets[(size_t)k]);
     for (int64_t i = 0; i < db->total; ++i)
         if (residues[i] >= alphabetLength)
             return fail(MIOPAL_ERR_BAD_ARGUMENT, "residue %d out of range for alphabet %d", residues[i], alphabetLength);

@@ -70,7 +70,7 @@ __global__ void scatter_kernel(const int32_t* viewScore, const uint8_t* viewOver
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nTargets) return;
     out[ids[k] - sliceStart] = viewScore[k];
-    if (viewOverflow[k]) atomicAdd(overflowCount, 1);
+    if (overflowCount != nullptr && viewOverflow[k]) atomicAdd(overflowCount, 1);
 }
 
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream) {

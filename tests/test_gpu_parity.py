@@ -156,6 +156,24 @@ def test_sw_int16_saturation(capi):
     compare(gpu, ref, "score", "saturation")
 
 
+def test_sw_lane_width_ladder(capi):
+    # half-float lanes are exact below 2048, int16 lanes below 32767, then int32:
+    # thousands of close homologues push most targets past the first rung (so the
+    # whole view is redone with int16 lanes), a few past the second
+    rng = np.random.default_rng(14)
+    q = _data.random_protein(rng, 6500)
+    short = q[:480].copy()
+    seqs = [_data.mutate(rng, short, 0.08) for _ in range(2300)]
+    seqs += [_data.random_protein(rng, int(n)) for n in rng.integers(20, 600, size=700)]
+    seqs += [q.copy(), _data.mutate(rng, q, 0.02)]
+    res, off = _oracle.flatten(seqs)
+    for query in (short, q):
+        gpu, ref = run_both(capi, query, res, off, B62, 3, 1, "score", "sw")
+        assert (ref["score"] >= 2048).sum() > 2048
+        compare(gpu, ref, "score", f"ladder Q={len(query)}")
+    assert ref["score"].max() > 32767
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_long_targets_overflow_ladder(capi, algo):
     # shape of src/pyopal/tests/test_aligner.py:24-37 (lengths 1000..35000,
