@@ -80,6 +80,19 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
                  int* alignmentLength);
 
 /*
+ * Same search with the alignments returned as ONE malloc'ed buffer
+ * (*operations, caller frees) and operationOffsets[end - start + 1]: target k's
+ * operations are (*operations)[operationOffsets[k] .. operationOffsets[k+1]).
+ * This is the bulk form of the per-result `alignment` pointers of
+ * OpalSearchResult (src/pyopal/opal.pxd:24-32): one allocation instead of N.
+ */
+int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                     int gapExt, const int* scoreMatrix, int alphabetLength, int searchType,
+                     int mode, int64_t start, int64_t end, int* score, int* endTarget,
+                     int* endQuery, int* startTarget, int* startQuery,
+                     unsigned char** operations, int64_t* operationOffsets);
+
+/*
  * Score-only search whose int32 results stay in HBM: `deviceScores` is a
  * device pointer with end - start entries (database order), `stream` a
  * hipStream_t (NULL = the null stream). The call only enqueues work; the

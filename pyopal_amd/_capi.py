@@ -45,7 +45,7 @@ EXPORTS = [
     # miopal.h
     "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
-    "miopalSearch", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
+    "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalSearchResults",
 ]
 
@@ -101,6 +101,10 @@ def lib() -> ctypes.CDLL:
         L.miopalSearch.restype = c_int
         L.miopalSearch.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
                                    c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]
+        L.miopalSearchFlat.restype = c_int
+        L.miopalSearchFlat.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
+                                       c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       ctypes.POINTER(c_vp), c_vp]
         L.miopalSearchDeviceScores.restype = c_int
         L.miopalSearchDeviceScores.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int,
                                                c_i64, c_i64, c_vp, c_vp]
@@ -140,6 +144,28 @@ def raise_for(rc: int) -> None:
 
 def _ptr(a: typing.Optional[np.ndarray]):
     return None if a is None else a.ctypes.data
+
+
+class _LazyAlignments:
+    """List-like view of the per-target operation arrays inside the flat buffer."""
+
+    def __init__(self, flat: np.ndarray, offsets: np.ndarray):
+        self._flat = flat
+        self._off = offsets
+
+    def __len__(self):
+        return len(self._off) - 1
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        return self._flat[self._off[k]:self._off[k + 1]]
+
+    def __iter__(self):
+        for k in range(len(self)):
+            yield self[k]
 
 
 class DeviceDatabase:
@@ -185,34 +211,33 @@ class DeviceDatabase:
         S = np.ascontiguousarray(matrix, dtype=np.int32)
         st = SEARCH[mode]
         out = {"score": np.zeros(n, dtype=np.int32)}
-        et = eq = s_t = s_q = alen = None
-        aptr = None
+        et = eq = s_t = s_q = aoff = None
+        ops_ptr = ctypes.c_void_p()
         if st >= 1:
             et = np.full(n, -1, dtype=np.int32)
             eq = np.full(n, -1, dtype=np.int32)
         if st == 2:
             s_t = np.full(n, -1, dtype=np.int32)
             s_q = np.full(n, -1, dtype=np.int32)
-            alen = np.zeros(n, dtype=np.int32)
-            aptr = (ctypes.c_void_p * max(n, 1))()
-        rc = lib().miopalSearch(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
-                                self.alphabet_length, st, MODE[algorithm], start, end,
-                                _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),
-                                ctypes.cast(aptr, ctypes.c_void_p) if aptr is not None else None,
-                                _ptr(alen))
+            aoff = np.zeros(n + 1, dtype=np.int64)
+        rc = lib().miopalSearchFlat(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
+                                    self.alphabet_length, st, MODE[algorithm], start, end,
+                                    _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),
+                                    ctypes.byref(ops_ptr), _ptr(aoff))
         raise_for(rc)
         if st >= 1:
             out.update(end_t=et, end_q=eq)
         if st == 2:
-            alns = []
-            for k in range(n):
-                if aptr[k]:
-                    buf = (ctypes.c_ubyte * int(alen[k])).from_address(aptr[k])
-                    alns.append(np.frombuffer(bytes(buf), dtype=np.uint8).copy())
-                    _libc.free(aptr[k])
-                else:
-                    alns.append(np.zeros(0, dtype=np.uint8))
-            out.update(start_t=s_t, start_q=s_q, aln=alns)
+            total = int(aoff[-1]) if n else 0
+            if ops_ptr.value and total:
+                flat = np.frombuffer((ctypes.c_ubyte * total).from_address(ops_ptr.value),
+                                     dtype=np.uint8).copy()
+            else:
+                flat = np.zeros(0, dtype=np.uint8)
+            if ops_ptr.value:
+                _libc.free(ops_ptr)
+            out.update(start_t=s_t, start_q=s_q, aln_flat=flat, aln_off=aoff,
+                       aln=_LazyAlignments(flat, aoff))
         return out
 
     def search_device_scores(self, query: np.ndarray, matrix: np.ndarray, device_ptr: int,

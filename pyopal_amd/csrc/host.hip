@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <list>
 #include <map>
 #include <memory>
@@ -55,6 +56,23 @@ int fail(int code, const char* fmt, ...) {
         int _rc = (expr);     \
         if (_rc) return _rc;  \
     } while (0)
+
+struct PhaseTimer {
+    bool on;
+    double t0;
+    static double now() {
+        timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return ts.tv_sec + 1e-9 * ts.tv_nsec;
+    }
+    PhaseTimer() : on(getenv("MIOPAL_PHASE_TIMING") != nullptr), t0(now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[miopal] %-28s %8.3f ms\n", what, (t - t0) * 1e3);
+        t0 = t;
+    }
+};
 
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 6ll << 30;  // bytes of direction workspace per traceback batch
@@ -684,17 +702,20 @@ int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int query
     return s.scorePass((int32_t*)deviceScores, nullptr, nullptr);
 }
 
-int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
-                 const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
-                 int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
-                 int* startQuery, unsigned char** alignment, int* alignmentLength) {
+static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
+                      const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
+                      int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
+                      int* startQuery, unsigned char** alignment, int* alignmentLength,
+                      std::vector<uint8_t>* flatOps, int64_t* flatOff) {
     RC_TRY(validate(db, query, queryLength, scoreMatrix, alphabetLength, searchType, mode, start, end));
     const int64_t n = end - start;
     if (n == 0) return 0;
     if (!score) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null score output");
     if (searchType >= OPAL_SEARCH_SCORE_END && (!endTarget || !endQuery))
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "null end-location outputs");
-    if (searchType == OPAL_SEARCH_ALIGNMENT && (!startTarget || !startQuery || !alignment || !alignmentLength))
+    const bool flat = flatOps != nullptr;
+    if (searchType == OPAL_SEARCH_ALIGNMENT &&
+        (!startTarget || !startQuery || (flat ? !flatOff : (!alignment || !alignmentLength))))
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
     HIP_TRY(hipSetDevice(db->device));
     WorkspaceLease lease(db);
@@ -704,6 +725,7 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
     Search s{db, ws, stream, query, queryLength, gapOpen, gapExt, alphabetLength, searchType, mode,
              scoreMatrix, start, end, n};
     RC_TRY(s.prepare());
+    PhaseTimer pt;
 
     void *ps, *pi = nullptr, *pj = nullptr;
     RC_TRY(ws->get(kScore, (size_t)n * sizeof(int32_t), &ps));
@@ -719,6 +741,7 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
         RC_TRY(download(endTarget, (const int*)pj, (size_t)n, stream));
     }
     HIP_TRY(hipStreamSynchronize(stream));
+    pt.mark("score/end pass + D2H");
     if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
 
     // ---- start locations: reversed prefixes anchored on the end cell ----------
@@ -726,9 +749,14 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
     RC_TRY(s.rulesFor(mode, &fr));
     for (int64_t k = 0; k < n; ++k) {
         startQuery[k] = startTarget[k] = -1;
-        alignment[k] = nullptr;
-        alignmentLength[k] = 0;
+        if (flat) {
+            flatOff[k + 1] = 0;  // lengths first, prefix-summed at the end
+        } else {
+            alignment[k] = nullptr;
+            alignmentLength[k] = 0;
+        }
     }
+    if (flat) flatOff[0] = 0;
     std::vector<int64_t> live;  // slots with a non-empty alignment
     for (int64_t k = 0; k < n; ++k)
         if (endQuery[k] >= 0 && endTarget[k] >= 0) live.push_back(k);
@@ -770,6 +798,7 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
         }
     }
 
+    pt.mark("start-location pass");
     // ---- traceback on [start..end] rectangles, batched by direction workspace --
     size_t pos = 0;
     while (pos < live.size()) {
@@ -817,24 +846,65 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
         wa.opsOff = (const int64_t*)poff;
         wa.opsLen = (int32_t*)plen;
         HIP_TRY(launchWalk(wa, stream));
+        if (pt.on) { HIP_TRY(hipStreamSynchronize(stream)); pt.mark("  trace + walk kernels"); }
         std::vector<uint8_t> ops((size_t)opsOff.back());
         std::vector<int32_t> lens(jobs.size()), tscore(jobs.size());
         RC_TRY(download(ops.data(), (const uint8_t*)po, ops.size(), stream));
         RC_TRY(download(lens.data(), (const int32_t*)plen, lens.size(), stream));
         RC_TRY(download(tscore.data(), (const int32_t*)pscore, tscore.size(), stream));
         HIP_TRY(hipStreamSynchronize(stream));
+        pt.mark("  ops D2H");
         for (size_t x = 0; x < jobs.size(); ++x) {
             const int64_t k = live[first + x];
             if (tscore[x] != score[k])
                 return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
                             tscore[x], score[k], (long long)(start + k));
             const int len = lens[x];
-            unsigned char* buf = (unsigned char*)malloc((size_t)std::max(len, 1));
-            if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-            memcpy(buf, ops.data() + opsOff[x + 1] - len, (size_t)len);
-            alignment[k] = buf;
-            alignmentLength[k] = len;
+            const uint8_t* src = ops.data() + opsOff[x + 1] - len;
+            if (flat) {
+                // jobs are visited in increasing target order, so appending keeps slice order
+                flatOps->insert(flatOps->end(), src, src + len);
+                flatOff[k + 1] = len;
+            } else {
+                unsigned char* buf = (unsigned char*)malloc((size_t)std::max(len, 1));
+                if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+                memcpy(buf, src, (size_t)len);
+                alignment[k] = buf;
+                alignmentLength[k] = len;
+            }
         }
+        pt.mark("  host copy-out");
+    }
+    if (flat)
+        for (int64_t k = 0; k < n; ++k) flatOff[k + 1] += flatOff[k];
+    return 0;
+}
+
+int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
+                 const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
+                 int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
+                 int* startQuery, unsigned char** alignment, int* alignmentLength) {
+    return searchImpl(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType, mode,
+                      start, end, score, endTarget, endQuery, startTarget, startQuery, alignment,
+                      alignmentLength, nullptr, nullptr);
+}
+
+int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
+                     const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
+                     int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
+                     int* startQuery, unsigned char** operations, int64_t* operationOffsets) {
+    std::vector<uint8_t> ops;
+    const bool full = searchType == OPAL_SEARCH_ALIGNMENT;
+    if (full && !operations) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
+    if (operations) *operations = nullptr;
+    RC_TRY(searchImpl(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType, mode,
+                      start, end, score, endTarget, endQuery, startTarget, startQuery, nullptr, nullptr,
+                      full ? &ops : nullptr, full ? operationOffsets : nullptr));
+    if (full && end > start) {
+        unsigned char* buf = (unsigned char*)malloc(std::max<size_t>(ops.size(), 1));
+        if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+        if (!ops.empty()) memcpy(buf, ops.data(), ops.size());
+        *operations = buf;
     }
     return 0;
 }

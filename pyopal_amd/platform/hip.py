@@ -85,6 +85,8 @@ def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, 
     start_t = out["start_t"].tolist()
     lengths = database._get_lengths()
     qlen = len(encoded)
+    ops_all = out["aln_flat"].tobytes()
+    ops_off = out["aln_off"].tolist()
     for k, j in enumerate(indices):
         r = FullResult.__new__(FullResult)
         r._target_index = j
@@ -94,7 +96,7 @@ def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, 
         r._target_end = end_t[k]
         r._query_start = start_q[k]
         r._target_start = start_t[k]
-        r._ops = out["aln"][k].tobytes()
+        r._ops = ops_all[ops_off[k]:ops_off[k + 1]]
         # recorded so that the coverage can be computed later (pyx.in:95-99)
         r._query_length = qlen
         r._target_length = int(lengths[j])
