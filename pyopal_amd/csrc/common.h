@@ -29,9 +29,13 @@ struct InterseqArgs {
     int nSymbols;              // A + 1
     int qPad;                  // nStrips * R
     int nStrips;
+    int qLen;                  // true query length (rows beyond it are padding)
     int gapOpen, gapExt;
+    int topGap, leftGap;       // border rules (DpRules)
+    int region;                // Region: where the answer is taken
+    const int32_t* lens;       // [nGroups * 128] target lengths, packed-view order (0 = absent)
     int32_t* score;            // [nGroups * 128], packed-view order
-    uint8_t* overflow;         // [nGroups * 128], 1 = lane saturated
+    uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -91,7 +95,18 @@ struct PackArgs {
 };
 
 // ---- launchers (defined next to their kernels) -----------------------------
-hipError_t launchInterseqSwScore(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, hipStream_t stream);
+enum InterseqFlavour : int {
+    kSwHalf = 0,              // Smith-Waterman, packed half floats (exact below 2048)
+    kSwInt16 = 1,             // Smith-Waterman, saturating int16
+    kSignedInt16 = 2,         // NW / HW / OV, signed saturating int16
+    kSignedInt16AllCells = 3  // anchored reverse pass: signed, every cell is a candidate
+};
+hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
+                          hipStream_t stream);
+hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSwInt16(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSigned(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);

@@ -140,6 +140,7 @@ struct View {
     std::vector<int32_t> ids;        // view position -> database index (packed part)
     std::vector<int32_t> longIds;    // targets always handled by the intra-sequence kernel
     int32_t* d_ids = nullptr;
+    int32_t* d_lens = nullptr;       // target lengths in view order, padded to whole groups
     uint2* d_pack = nullptr;
     int64_t* d_groupOff = nullptr;
     int* d_groupChunks = nullptr;
@@ -147,6 +148,7 @@ struct View {
     size_t deviceBytes = 0;
     ~View() {
         if (d_ids) (void)hipFree(d_ids);
+        if (d_lens) (void)hipFree(d_lens);
         if (d_pack) (void)hipFree(d_pack);
         if (d_groupOff) (void)hipFree(d_groupOff);
         if (d_groupChunks) (void)hipFree(d_groupChunks);
@@ -288,6 +290,10 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
         HIP_TRY(hipMalloc(&v->d_boundaryOff, boundaryOff.size() * sizeof(int64_t)));
         HIP_TRY(hipMalloc(&d_chunkPrefix, chunkPrefix.size() * sizeof(int64_t)));
         HIP_TRY(hipMemcpy(v->d_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        std::vector<int32_t> lens((size_t)v->nGroups * kGroupTargets, 0);
+        for (size_t k = 0; k < ids.size(); ++k) lens[k] = dbLen(db, ids[k]);
+        HIP_TRY(hipMalloc(&v->d_lens, lens.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(v->d_lens, lens.data(), lens.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(v->d_groupChunks, groupChunks.data(), groupChunks.size() * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(v->d_boundaryOff, boundaryOff.data(), boundaryOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -386,7 +392,7 @@ struct Search {
     }
 
     bool interseqUsable() const {
-        if (mode != OPAL_MODE_SW || searchType != OPAL_SEARCH_SCORE || Q <= 0) return false;
+        if (searchType != OPAL_SEARCH_SCORE || Q <= 0) return false;
         if (open < 0 || ext < 0) return false;
         if (maxScore > 16383 || minScore < -16383) return false;
         return true;
@@ -466,10 +472,29 @@ struct Search {
             const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
             const int qPad = nStrips * rows;
             const int nSym = A + 1;
-            // Lane arithmetic: packed half floats are exact for integers below 2048 and
-            // cost fewer instructions per cell (interseq.hip); saturating int16 is the
-            // second rung, the int32 intra-sequence kernel the last.
-            const bool halfFloat = useHalf && maxScore <= 1024 && minScore >= -1024;
+            // Lane arithmetic. Smith-Waterman: packed half floats are exact for integers
+            // below 2048 and cost fewer instructions per cell (interseq_impl.h); saturating
+            // int16 is the second rung, the int32 intra-sequence kernel the last. The other
+            // modes use signed int16 lanes; whether a target fits is known from its length:
+            //   every true H, E, F >= -(3*open + (Q + L)*ext)   and   H <= min(Q, L)*maxScore
+            const bool sw = mode == OPAL_MODE_SW;
+            const bool halfFloat = sw && useHalf && maxScore <= 1024 && minScore >= -1024;
+            const InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
+            if (!sw) {
+                const int64_t lowSafe = (32000 - 3 * (int64_t)open - (int64_t)Q * ext) / std::max(ext, 1);
+                const int64_t pos = std::max(maxScore, 0);
+                const bool qFits = (int64_t)Q * pos < 32000;
+                // view order is longest first: the targets that do not fit form a prefix,
+                // empty targets (closed forms of the border) a suffix
+                int k = 0;
+                for (; k < view->nPacked; ++k) {
+                    const int64_t L = dbLen(db, view->ids[k]);
+                    if (L > 0 && L <= lowSafe && (qFits || L * pos < 32000)) break;
+                    jobs.push_back(forwardJob(view->ids[k], rules));
+                }
+                for (int e = view->nPacked - 1; e >= k && dbLen(db, view->ids[e]) == 0; --e)
+                    jobs.push_back(forwardJob(view->ids[e], rules));
+            }
             // query profile: profile[t][i] = S[q_i][t]; padding symbol and padding rows can
             // never win a max: -32768 (int16) or -inf (half)
             auto enc = [&](int v) -> int16_t {
@@ -492,7 +517,7 @@ struct Search {
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
             const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
             const int64_t limit = halfFloat ? 2048 : 32767;
-            const bool mayOverflow = reach >= limit;
+            const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
             ia.pack = view->d_pack;
@@ -503,12 +528,19 @@ struct Search {
             ia.nSymbols = nSym;
             ia.qPad = qPad;
             ia.nStrips = nStrips;
+            ia.qLen = Q;
             ia.gapOpen = std::min(open, 32767);
             ia.gapExt = std::min(ext, 32767);
+            ia.topGap = r.topGap;
+            ia.leftGap = r.leftGap;
+            ia.region = r.region;
+            ia.lens = view->d_lens;
             ia.score = (int32_t*)vs;
-            ia.overflow = (uint8_t*)vo;
+            ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.boundaryOff = view->d_boundaryOff;
-            if (nStrips > 1) {
+            // strips of a group in flight (wavefronts per workgroup)
+            const int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
+            if ((nStrips + waves - 1) / waves > 1) {
                 void *b0, *b1;
                 const size_t bytes = (size_t)view->totalChunks * 4 * kLanes * sizeof(uint2);
                 RC_TRY(ws->get(kBoundary0, bytes, &b0));
@@ -523,14 +555,14 @@ struct Search {
                 HIP_TRY(hipEventCreate(&e1));
                 HIP_TRY(hipEventRecord(e0, stream));
             }
-            HIP_TRY(launchInterseqSwScore(ia, rows, halfFloat, stream));
+            HIP_TRY(launchInterseq(ia, rows, waves, flavour, stream));
             if (timed) {
                 HIP_TRY(hipEventRecord(e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
                 ws->timings.emplace_back(e0, e1);
                 db->lastTimed = ws;
             }
-            HIP_TRY(launchScatter(ia.score, ia.overflow, view->d_ids, view->nPacked, start, d_score,
+            HIP_TRY(launchScatter(ia.score, (const uint8_t*)vo, view->d_ids, view->nPacked, start, d_score,
                                   mayOverflow ? (int32_t*)ct : nullptr, stream));
             if (mayOverflow) {
                 int32_t count = 0;

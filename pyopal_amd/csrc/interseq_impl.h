@@ -1,0 +1,436 @@
+// Inter-sequence DP kernel for gfx950: scores of one query against 128 targets
+// per wavefront, for all four alignment modes. Included by the interseq_*.hip
+// translation units, one per arithmetic flavour (keeps hipcc builds parallel).
+//
+// Replaces the SIMD inner loop of opalSearchDatabase (declared
+// src/pyopal/opal.pxd:38-52; the SSE/AVX2 body lives in the absent
+// vendor/opal) for searchType = OPAL_SEARCH_SCORE.
+//
+// Mapping. SWIPE's "one SIMD lane = one database sequence" is widened to the
+// 64-lane wavefront, and every lane carries TWO targets in the halves of a
+// 32-bit VGPR (packed 16-bit arithmetic), so a wavefront advances 128 targets
+// by one database column per pass over the query rows. The query rows of a
+// strip (R <= 64) live in registers as H[R], E[R]; the substitution scores of
+// the strip ("query profile", one row per residue symbol) live in LDS and are
+// fetched with one ds_read_b128 per 8 rows per target.
+//
+// Long queries are cut into strips of R rows. The W wavefronts of a workgroup
+// work on the SAME 128 targets, wavefront w on strip w of the current round,
+// one 4-column chunk behind wavefront w-1 (a software pipeline along the
+// anti-diagonal of (strip, chunk)); the last row of a strip reaches the next
+// strip through a 2 KB LDS buffer, and only the hop from strip W-1 to strip 0 of
+// the next round goes through HBM, in [column][lane] order (512 B per
+// wavefront-column, coalesced). With W = 1 this degenerates to one wavefront per
+// group walking its strips in turn.
+//
+// Cell update, per pair of targets:
+//   h    = max(Hdiag + s, E[r], F)
+//   hmo  = h - open
+//   E[r] = max(E[r] - ext, hmo)        (gap consuming target residues)
+//   F    = max(F - ext, hmo)           (gap consuming query residues)
+// Arithmetic flavours (struct Arith*):
+//   ArithSwF16  Smith-Waterman, packed half floats (integers exact below 2048);
+//               E and F are floored at 0, so H needs no floor of its own, and
+//               v_pk_maximum3_f16 folds two max per cell: 7.5 ops + 1 v_perm.
+//   ArithSwI16  Smith-Waterman, saturating int16 with unsigned-saturating
+//               subtraction for the same floor: 9 ops + 1 v_perm.
+//   ArithI16    signed saturating int16 for NW / HW / OV and for the anchored
+//               reverse pass: 8 ops + 1 v_perm (+1 when every cell is a candidate).
+// A lane that reaches the limit of its flavour is flagged; the host recomputes
+// it with the next rung (int16, then the int32 intra-sequence kernel): the
+// reference's 8/16/32-bit ladder (src/pyopal/lib.pyx:1283-1289) on hardware that
+// has no packed 8-bit max. (ds_read_u16_d16[_hi] cannot build the {A, B} score
+// pair for free: with SRAM-ECC registers gfx950 d16 loads overwrite the whole
+// VGPR; measured.)
+#pragma once
+#include "common.h"
+
+namespace miopal {
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+static __device__ __forceinline__ uint32_t pk_add_sat_i16(uint32_t a, uint32_t b) {
+    s16x2 r = __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t pk_sub_sat_i16(uint32_t a, uint32_t b) {
+    s16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    s16x2 r = __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t pk_sub_sat_u16(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t pk_add_f16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
+}
+static __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    f16x2 r = __builtin_elementwise_maximum(
+        __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+        __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t dup16(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
+
+// ---- arithmetic flavours --------------------------------------------------------
+struct ArithSwI16 {
+    static constexpr bool kFloor = true;    // Smith-Waterman
+    static constexpr int kLimit = 0x7fff;   // a best at or above this may have clipped
+    uint32_t open2, ext2;
+    __device__ __forceinline__ ArithSwI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max_i16(pk_max_i16(d, e), f); }
+    __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
+        (void)held; (void)r;
+        best = pk_max_i16(best, h);
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_sub_sat_u16(h, open2); }
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_sub_sat_u16(h, open2); }
+    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_sub_sat_u16(h, ext2); }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(pk_sub_sat_u16(x, ext2), hmo); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, 0)); }
+    static __device__ __forceinline__ uint32_t lowest() { return 0u; }
+    static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
+};
+
+struct ArithSwF16 {
+    static constexpr bool kFloor = true;
+    static constexpr int kLimit = 2048;
+    uint32_t negOpen2, negExt2;
+    static __device__ __forceinline__ uint32_t pack(int v) {
+        const _Float16 h = (_Float16)(float)v;
+        return (uint32_t)__builtin_bit_cast(unsigned short, h) * 0x00010001u;
+    }
+    __device__ __forceinline__ ArithSwF16(int open, int ext) : negOpen2(pack(-min(open, 2048))), negExt2(pack(-min(ext, 2048))) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_f16(h, s); }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max3_f16(d, e, f); }
+    __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
+        if (r & 1) best = pk_max3_f16(best, held, h);
+        else held = h;
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max3_f16(a, b, b); }
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_max3_f16(pk_add_f16(h, negOpen2), 0u, 0u); }
+    // inside a cell the floor comes with the max3 of gap(), so the open step needs none
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_add_f16(h, negOpen2); }
+    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_max3_f16(pk_add_f16(h, negExt2), 0u, 0u); }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max3_f16(pk_add_f16(x, negExt2), hmo, 0u); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return pack(max(v, 0)); }
+    static __device__ __forceinline__ uint32_t lowest() { return 0u; }
+    static __device__ __forceinline__ int toInt(uint32_t half) {
+        return (int)(float)__builtin_bit_cast(_Float16, (unsigned short)half);
+    }
+};
+
+struct ArithI16 {
+    static constexpr bool kFloor = false;   // NW / HW / OV / anchored reverse pass
+    static constexpr int kLimit = 0x7fff;   // ranges are checked statically by the host
+    uint32_t open2, ext2;
+    __device__ __forceinline__ ArithI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max_i16(pk_max_i16(d, e), f); }
+    __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
+        (void)held; (void)r;
+        best = pk_max_i16(best, h);
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_sub_sat_i16(h, open2); }
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_sub_sat_i16(h, open2); }
+    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_sub_sat_i16(h, ext2); }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(pk_sub_sat_i16(x, ext2), hmo); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, -32768)); }
+    static __device__ __forceinline__ uint32_t lowest() { return 0x80008000u; }  // acts as -infinity
+    static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
+};
+
+// 16-byte slots per profile row in LDS: odd, so that the 16 lanes of a
+// ds_read_b128 lane group that hold different symbols land on different slots.
+template <int R>
+struct ProfileLayout {
+    static constexpr int kSlots = (R / 8) | 1;
+};
+
+// take the halves of `v` named by the 0 / 0xffff masks in `m`, keep `dst` elsewhere
+static __device__ __forceinline__ uint32_t selectHalves(uint32_t dst, uint32_t v, uint32_t m) {
+    return (dst & ~m) | (v & m);
+}
+
+// MULTI = false: the query fits one strip (no boundary traffic, no rounds).
+template <int R, typename Arith, int W, bool TRACK_ALL, bool MULTI>
+__global__ __launch_bounds__(W * kLanes)
+void interseq_kernel(InterseqArgs a) {
+    static_assert(MULTI || W == 1, "a single strip needs a single wavefront");
+    constexpr bool kRegions = !Arith::kFloor;  // Smith-Waterman flavours only know the all-cells maximum
+    constexpr int SLOTS = ProfileLayout<R>::kSlots;
+    constexpr int NB = R / 8;
+    constexpr int WB = W > 1 ? W : 1;
+    __shared__ uint4 ldsProf[W][(kMaxAlphabet + 1) * SLOTS];
+    __shared__ uint2 ldsBnd[WB][2][W > 1 ? 4 * kLanes : 1];
+    __shared__ uint32_t ldsOut[WB][W > 1 ? kLanes : 1];
+
+    const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x;  // one group of 128 targets per workgroup
+
+    uint4* prof = ldsProf[wave];
+    const uint2* pack = a.pack + a.groupOff[g];
+    const int nChunks = a.groupChunks[g];
+    const Arith ar(a.gapOpen, a.gapExt);
+    const uint4* gprof = reinterpret_cast<const uint4*>(a.profile);
+    const int rowSlotsGlobal = a.qPad / 8;
+    const int nStrips = MULTI ? a.nStrips : 1;
+    const int Q = a.qLen;
+    const bool topGap = a.topGap, leftGap = a.leftGap;
+    const int region = kRegions ? a.region : (int)kAllCells;
+    const int open = a.gapOpen, ext = a.gapExt;
+
+    // per-lane target lengths (NW / OV take answers at each target's own last column)
+    const size_t base = (size_t)g * kGroupTargets;
+    int lenA = 0, lenB = 0;
+    if (kRegions && (!TRACK_ALL || region != kAllCells)) {
+        lenA = a.lens[base + lane];
+        lenB = a.lens[base + kLanes + lane];
+    }
+
+    uint32_t best = Arith::lowest(), held = Arith::lowest();  // maximum over all cells (TRACK_ALL)
+    uint32_t ans = Arith::lowest();                            // answer of the other regions
+    uint32_t H[R], E[R];
+
+    const int lastStrip = nStrips - 1;
+    const int rl = Q - 1 - lastStrip * R;  // row of the last query residue inside the last strip
+    const int nRounds = (nStrips + W - 1) / W;
+    const int nSteps = nChunks + (W - 1);
+
+    for (int rho = 0; rho < nRounds; ++rho) {
+        const int s = rho * W + wave;
+        const bool active = s < nStrips;
+        const bool isLast = s == lastStrip;
+        const bool inGlobal = MULTI && active && s > 0 && wave == 0;  // boundary of the previous round, from HBM
+        const bool inLds = MULTI && active && s > 0 && wave > 0;      // boundary of the wavefront above, from LDS
+        const bool outGlobal = MULTI && active && s + 1 < nStrips && wave == W - 1;
+        const bool outLds = MULTI && active && s + 1 < nStrips && wave < W - 1;
+        const uint2* bin = nullptr;
+        uint2* bout = nullptr;
+        if (MULTI && nRounds > 1) {
+            bin = a.boundary[(rho + 1) & 1] + a.boundaryOff[g];
+            bout = a.boundary[rho & 1] + a.boundaryOff[g];
+        }
+
+        uint32_t hdiagTop = Arith::lowest();
+        uint32_t topH = 0;
+        if (active) {
+            // stage this strip's slice of the query profile into the wavefront's LDS region
+            for (int idx = lane; idx < a.nSymbols * (R / 8); idx += kLanes) {
+                const int t = idx / (R / 8), k = idx - t * (R / 8);
+                prof[t * SLOTS + k] = gprof[t * rowSlotsGlobal + s * (R / 8) + k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // column -1: left border H[i][-1] and the E it induces in column 0
+            const int i0 = s * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                uint32_t hl;
+                if (Arith::kFloor) hl = 0u;
+                else if (i0 + r >= Q) hl = Arith::lowest();
+                else hl = ar.fromInt(leftGap ? -(open + (i0 + r) * ext) : 0);
+                H[r] = hl;
+                E[r] = ar.afterOpen(hl);
+            }
+            // H[i0-1][-1]: diagonal of the strip's first row in column 0
+            if (Arith::kFloor) hdiagTop = 0u;
+            else hdiagTop = (s == 0 || !leftGap) ? ar.fromInt(0) : ar.fromInt(-(open + (i0 - 1) * ext));
+            topH = ar.fromInt(topGap ? -open : 0);  // H[-1][0]
+        }
+
+        uint2 cur = {0, 0}, nxt = {0, 0};
+        uint2 n0 = {0, 0}, n1 = {0, 0}, n2 = {0, 0}, n3 = {0, 0};
+        if (active) {
+            cur = pack[lane];
+            if (inGlobal) {
+                n0 = bin[0 * kLanes + lane];
+                n1 = bin[1 * kLanes + lane];
+                n2 = bin[2 * kLanes + lane];
+                n3 = bin[3 * kLanes + lane];
+            }
+        }
+
+        for (int tau = 0; tau < nSteps; ++tau) {
+            const int c = tau - wave;
+            if (active && c >= 0 && c < nChunks) {
+                uint2 b0 = n0, b1 = n1, b2 = n2, b3 = n3;
+                if (W > 1 && inLds) {
+                    const uint2* p = ldsBnd[wave - 1][c & 1] + lane;
+                    b0 = p[0 * kLanes];
+                    b1 = p[1 * kLanes];
+                    b2 = p[2 * kLanes];
+                    b3 = p[3 * kLanes];
+                }
+                if (c + 1 < nChunks) {
+                    nxt = pack[(size_t)(c + 1) * kLanes + lane];
+                    if (MULTI && inGlobal) {
+                        const uint2* p = bin + (size_t)(c + 1) * 4 * kLanes + lane;
+                        n0 = p[0 * kLanes];
+                        n1 = p[1 * kLanes];
+                        n2 = p[2 * kLanes];
+                        n3 = p[3 * kLanes];
+                    }
+                }
+                uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int j = c * 4 + cc;
+                    const uint32_t tA = ra & 0xffu, tB = rb & 0xffu;
+                    ra >>= 8;
+                    rb >>= 8;
+                    const uint4* pa = prof + tA * SLOTS;
+                    const uint4* pb = prof + tB * SLOTS;
+                    // row above the strip: H[i0-1][j-1] (diagonal) and the F entering row i0
+                    uint32_t diag = hdiagTop;
+                    uint32_t f;
+                    if (!MULTI || s == 0) {
+                        hdiagTop = topH;
+                        f = ar.afterOpen(topH);
+                        if (topGap) topH = ar.afterExt(topH);
+                    } else {
+                        hdiagTop = b0.x;
+                        f = b0.y;
+                    }
+                    // Profile rows are fetched one 8-row block ahead of their use; the compiler
+                    // barrier at the end of each block keeps hipcc from hoisting every
+                    // ds_read_b128 and v_perm to the top of the column (~60 VGPRs, one wave
+                    // of occupancy).
+                    uint4 va[NB], vb[NB];
+                    va[0] = pa[0];
+                    vb[0] = pb[0];
+                    // {A's score, B's score} for query row r
+                    auto score = [&](int r) -> uint32_t {
+                        const uint4 x = va[r >> 3], y = vb[r >> 3];
+                        const int k = (r & 7) >> 1;
+                        const uint32_t wa = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                        const uint32_t wb = k == 0 ? y.x : k == 1 ? y.y : k == 2 ? y.z : y.w;
+                        return __builtin_amdgcn_perm(wb, wa, (r & 1) ? 0x07060302u : 0x05040100u);
+                    };
+                    uint32_t dsum = ar.addScore(diag, score(0));
+#pragma unroll
+                    for (int r8 = 0; r8 < NB; ++r8) {
+                        if (r8 + 1 < NB) {
+                            va[r8 + 1] = pa[r8 + 1];
+                            vb[r8 + 1] = pb[r8 + 1];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int r = r8 * 8 + k;
+                            // consume the old H[r] (diagonal of row r+1) before H[r] is rewritten
+                            uint32_t dnext = 0;
+                            if (r + 1 < R) dnext = ar.addScore(H[r], score(r + 1));
+                            const uint32_t h = ar.hmax(dsum, E[r], f);
+                            if (TRACK_ALL) ar.track(best, held, h, r);
+                            const uint32_t hmo = ar.cellOpen(h);
+                            E[r] = ar.gap(E[r], hmo);
+                            f = ar.gap(f, hmo);
+                            H[r] = h;
+                            dsum = dnext;
+                        }
+                        // pins the schedule: the block's cells are finished before the loads
+                        // (and v_perm) of the block after next may start
+                        asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                    }
+                    if (outGlobal) bout[((size_t)c * 4 + cc) * kLanes + lane] = make_uint2(H[R - 1], f);
+                    if (W > 1 && outLds) ldsBnd[wave][c & 1][cc * kLanes + lane] = make_uint2(H[R - 1], f);
+                    if (MULTI) {
+                        b0 = b1;
+                        b1 = b2;
+                        b2 = b3;
+                    }
+
+                    // ---- answers on the last query row / each target's last column ----
+                    if (kRegions && (!TRACK_ALL || region != kAllCells)) {
+                        const uint32_t lastMask = ((j == lenA - 1) ? 0x0000ffffu : 0u) |
+                                                  ((j == lenB - 1) ? 0xffff0000u : 0u);
+                        if (isLast) {
+                            uint32_t hq = H[0];
+#pragma unroll
+                            for (int r = 1; r < R; ++r)
+                                if (r == rl) hq = H[r];
+                            if (region == kLastCell) ans = selectHalves(ans, hq, lastMask);
+                            else ans = ar.max2(ans, hq);  // last row; padded columns never exceed real ones
+                        }
+                        if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastMask != 0) != 0) {
+                            // some lane is on its target's last column: maximum over this strip's rows
+                            uint32_t cm = H[0];
+#pragma unroll
+                            for (int r = 1; r < R; ++r) cm = ar.max2(cm, H[r]);
+                            ans = selectHalves(ans, ar.max2(ans, cm), lastMask);
+                        }
+                    }
+                }
+                cur = nxt;
+            }
+            if (W > 1) __syncthreads();
+        }
+        if (MULTI && nRounds > 1) {
+            // the next round's first strip reads what this round's last strip wrote to HBM
+            __threadfence();
+            if (W > 1) __syncthreads();
+        }
+    }
+
+    // ---- combine the wavefronts' partial answers ---------------------------------
+    uint32_t res = (TRACK_ALL && region == kAllCells) ? best : ans;
+    if (W > 1) {
+        ldsOut[wave][lane] = res;
+        __syncthreads();
+        if (wave != 0) return;
+        for (int w = 1; w < W; ++w) res = ar.max2(res, ldsOut[w][lane]);
+    }
+    const int lo = Arith::toInt(res & 0xffffu), hi = Arith::toInt(res >> 16);
+    a.score[base + lane] = lo;
+    a.score[base + kLanes + lane] = hi;
+    if (a.overflow) {
+        a.overflow[base + lane] = lo >= Arith::kLimit;
+        a.overflow[base + kLanes + lane] = hi >= Arith::kLimit;
+    }
+}
+
+template <int R, typename Arith, bool TRACK_ALL>
+static hipError_t launchW(const InterseqArgs& a, int waves, hipStream_t stream) {
+    const dim3 grid(a.nGroups);
+    if (a.nStrips == 1) {
+        hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, false>), grid, dim3(kLanes), 0, stream, a);
+        return hipGetLastError();
+    }
+    switch (waves) {
+        case 1: hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, true>), grid, dim3(1 * kLanes), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((interseq_kernel<R, Arith, 2, TRACK_ALL, true>), grid, dim3(2 * kLanes), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((interseq_kernel<R, Arith, 4, TRACK_ALL, true>), grid, dim3(4 * kLanes), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((interseq_kernel<R, Arith, 8, TRACK_ALL, true>), grid, dim3(8 * kLanes), 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Rows per strip are a multiple of 8 (one ds_read_b128 = 8 16-bit scores);
+// `waves` (1, 2, 4 or 8) is the number of strips of a group in flight.
+template <typename Arith, bool TRACK_ALL>
+static hipError_t launchFlavour(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
+    switch (rowsPerStrip) {
+        case 8: return launchW<8, Arith, TRACK_ALL>(a, waves, stream);
+        case 16: return launchW<16, Arith, TRACK_ALL>(a, waves, stream);
+        case 24: return launchW<24, Arith, TRACK_ALL>(a, waves, stream);
+        case 32: return launchW<32, Arith, TRACK_ALL>(a, waves, stream);
+        case 40: return launchW<40, Arith, TRACK_ALL>(a, waves, stream);
+        case 48: return launchW<48, Arith, TRACK_ALL>(a, waves, stream);
+        case 56: return launchW<56, Arith, TRACK_ALL>(a, waves, stream);
+        case 64: return launchW<64, Arith, TRACK_ALL>(a, waves, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace miopal
