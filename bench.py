@@ -146,11 +146,11 @@ def main():
                 "traffic": pmc_traffic(),
                 "traffic_source": "profiles/r01_pmc_interseq_sw_score.json (separate rocprofv3 --pmc passes "
                                   "FETCH_SIZE x2 + WRITE_SIZE, same kernel and workload)",
-                "kernel": "interseq_sw_score<56,false>",
+                "kernel": "interseq_pair_kernel<56, ArithSwF16>",
                 "kernel_ms": round(k_ms, 4),
                 "kernel_gcups": round(float(Q) * N * L / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                 "algorithmic_bytes": alg_bytes,
-                "note": "integer-VALU-bound by construction (about 5 packed VALU ops per cell, "
+                "note": "integer-VALU-bound by construction (about 4 packed VALU ops per cell, "
                         "0.02 B/cell): see DESIGN.md",
             },
             "db_build_s": round(build_s, 3),

@@ -36,6 +36,7 @@ struct InterseqArgs {
     const int32_t* lens;       // [nGroups * 128] target lengths, packed-view order (0 = absent)
     int32_t* score;            // [nGroups * 128], packed-view order
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
+    int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -103,6 +104,12 @@ enum InterseqFlavour : int {
 };
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
                           hipStream_t stream);
+// pair-indexed LDS profile (single strip, Smith-Waterman); false = table does not fit LDS
+bool interseqPairFits(int rowsPerStrip, int nSymbols);
+hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, int computeUnits,
+                              hipStream_t stream);
+hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSwInt16(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSigned(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);

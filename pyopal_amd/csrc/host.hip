@@ -85,7 +85,7 @@ constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent st
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kSlots
 };
 
 struct Workspace {
@@ -164,6 +164,7 @@ struct MiopalDb {
     int64_t count = 0;
     int64_t total = 0;
     int64_t maxLen = 0;            // longest sequence (range checks)
+    int computeUnits = 256;
     std::vector<int64_t> offsets;  // host copy, [count + 1]
     uint8_t* d_residues = nullptr;
     int64_t* d_offsets = nullptr;
@@ -555,7 +556,17 @@ struct Search {
                 HIP_TRY(hipEventCreate(&e1));
                 HIP_TRY(hipEventRecord(e0, stream));
             }
-            HIP_TRY(launchInterseq(ia, rows, waves, flavour, stream));
+            // one strip + Smith-Waterman: the pair-indexed LDS profile saves the v_perm per cell
+            const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
+            if (sw && nStrips == 1 && !(noPair && noPair[0] == '1') && interseqPairFits(rows, nSym)) {
+                void* wc;
+                RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
+                HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
+                ia.workCounter = (int*)wc;
+                HIP_TRY(launchInterseqPair(ia, rows, halfFloat, db->computeUnits, stream));
+            }
+            else
+                HIP_TRY(launchInterseq(ia, rows, waves, flavour, stream));
             if (timed) {
                 HIP_TRY(hipEventRecord(e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
@@ -610,6 +621,11 @@ int createCommon(MiopalDb** out, const unsigned char* residues, const std::vecto
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<MiopalDb> db(new MiopalDb());
     db->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            db->computeUnits = prop.multiProcessorCount;
+    }
     db->alphabet = alphabetLength;
     db->count = count;
     db->offsets = offsets;

@@ -15,4 +15,16 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
     return hipErrorInvalidValue;
 }
 
+bool interseqPairFits(int rowsPerStrip, int nSymbols) {
+    const size_t bytes = (size_t)nSymbols * nSymbols * (size_t)((rowsPerStrip / 4) | 1) * 16;
+    return bytes <= 158 * 1024;  // leaves the runtime a little of the 160 KB
+}
+
+hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, int computeUnits,
+                              hipStream_t stream) {
+    if (a.nGroups <= 0) return hipSuccess;
+    return halfFloat ? launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream)
+                     : launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
+}
+
 }  // namespace miopal

@@ -43,6 +43,8 @@
 // pair for free: with SRAM-ECC registers gfx950 d16 loads overwrite the whole
 // VGPR; measured.)
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace miopal {
@@ -431,6 +433,157 @@ static hipError_t launchFlavour(const InterseqArgs& a, int rowsPerStrip, int wav
         case 64: return launchW<64, Arith, TRACK_ALL>(a, waves, stream);
     }
     return hipErrorInvalidValue;
+}
+
+
+// ---- single-strip Smith-Waterman with a pair-indexed profile --------------------
+// The {A's score, B's score} pair of a query row depends on the query row and on the
+// two residues (tA, tB) only, so for a query that fits one strip the whole table
+//     pairs[tA * nSymbols + tB][r] = { S[q_r][tA], S[q_r][tB] }
+// fits the CU's 160 KB of LDS (625 rows x 60 dwords for the 24-letter protein
+// alphabet and R = 56). One ds_read_b128 then delivers four ready-made operands and
+// the v_perm_b32 per cell pair disappears (about 11 % of the VALU work). The table
+// is built once per workgroup, so workgroups are persistent: kPairWaves wavefronts
+// each pull groups from a shared counter until none is left.
+constexpr int kPairWaves = 12;  // 3 per SIMD at <= 168 VGPRs
+
+template <int R>
+struct PairLayout {
+    static constexpr int kRowSlots = (R / 4) | 1;  // 16-byte slots per row, odd: rows start on different slots
+    static __host__ __device__ constexpr size_t bytes(int nSymbols) {
+        return (size_t)nSymbols * nSymbols * kRowSlots * 16;
+    }
+};
+
+template <int R, typename Arith>
+__global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_kernel(InterseqArgs a) {
+    constexpr int SLOTS = PairLayout<R>::kRowSlots;
+    constexpr int NB4 = R / 4;
+    extern __shared__ uint4 pairs[];
+
+    const int lane = threadIdx.x & 63;
+    const int nSym = a.nSymbols;
+    const Arith ar(a.gapOpen, a.gapExt);
+
+    // build the table: one thread per (pair row, 2 query rows)
+    {
+        const uint32_t* gw = reinterpret_cast<const uint32_t*>(a.profile);
+        uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
+        const int rowWords = a.qPad / 2;
+        const int total = nSym * nSym * (R / 2);
+        for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
+            const int row = idx / (R / 2), k = idx - row * (R / 2);
+            const int tA = row / nSym, tB = row - tA * nSym;
+            const uint32_t wa = gw[tA * rowWords + k], wb = gw[tB * rowWords + k];
+            pw[row * (SLOTS * 4) + 2 * k] = __builtin_amdgcn_perm(wb, wa, 0x05040100u);
+            pw[row * (SLOTS * 4) + 2 * k + 1] = __builtin_amdgcn_perm(wb, wa, 0x07060302u);
+        }
+    }
+    __syncthreads();
+
+    // groups are handed out dynamically (longest first), so wavefronts finish together
+    for (;;) {
+        int g = 0;
+        if (lane == 0) g = atomicAdd(a.workCounter, 1);
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g >= a.nGroups) break;
+        const uint2* pack = a.pack + a.groupOff[g];
+        const int nChunks = a.groupChunks[g];
+        uint32_t best = 0u, held = 0u;
+        uint32_t H[R], E[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            H[r] = 0u;
+            E[r] = 0u;
+        }
+        uint2 cur = pack[lane];
+        for (int c = 0; c < nChunks; ++c) {
+            uint2 nxt = {0, 0};
+            if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+            uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+            for (int cc = 0; cc < 4; ++cc) {
+                const uint32_t tA = ra & 0xffu, tB = rb & 0xffu;
+                ra >>= 8;
+                rb >>= 8;
+                const uint4* prow = pairs + (tA * nSym + tB) * SLOTS;
+                uint32_t f = 0u;
+                uint4 v[NB4];
+                v[0] = prow[0];
+                auto score = [&](int r) -> uint32_t {
+                    const uint4 x = v[r >> 2];
+                    const int k = r & 3;
+                    return k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                };
+                uint32_t dsum = ar.addScore(0u, score(0));
+#pragma unroll
+                for (int r4 = 0; r4 < NB4; ++r4) {
+                    if (r4 + 1 < NB4) v[r4 + 1] = prow[r4 + 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = r4 * 4 + k;
+                        uint32_t dnext = 0;
+                        if (r + 1 < R) dnext = ar.addScore(H[r], score(r + 1));
+                        const uint32_t h = ar.hmax(dsum, E[r], f);
+                        ar.track(best, held, h, r);
+                        const uint32_t hmo = ar.cellOpen(h);
+                        E[r] = ar.gap(E[r], hmo);
+                        f = ar.gap(f, hmo);
+                        H[r] = h;
+                        dsum = dnext;
+                    }
+                    if (r4 & 1) asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                }
+            }
+            cur = nxt;
+        }
+        const int lo = Arith::toInt(best & 0xffffu), hi = Arith::toInt(best >> 16);
+        const size_t base = (size_t)g * kGroupTargets;
+        a.score[base + lane] = lo;
+        a.score[base + kLanes + lane] = hi;
+        if (a.overflow) {
+            a.overflow[base + lane] = lo >= Arith::kLimit;
+            a.overflow[base + kLanes + lane] = hi >= Arith::kLimit;
+        }
+    }
+}
+
+template <int R, typename Arith>
+static hipError_t launchPairR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols);
+    static bool configured = false;  // benign race: the attribute is idempotent
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_kernel<R, Arith>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
+    hipLaunchKernelGGL((interseq_pair_kernel<R, Arith>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Smith-Waterman, one strip, pair-indexed profile. Returns hipErrorInvalidValue when
+// the table does not fit LDS (the caller then uses the v_perm variant).
+template <typename Arith>
+static hipError_t launchPairFlavour(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    if (a.nStrips != 1) return hipErrorInvalidValue;
+    switch (rowsPerStrip) {
+        case 8: return launchPairR<8, Arith>(a, computeUnits, stream);
+        case 16: return launchPairR<16, Arith>(a, computeUnits, stream);
+        case 24: return launchPairR<24, Arith>(a, computeUnits, stream);
+        case 32: return launchPairR<32, Arith>(a, computeUnits, stream);
+        case 40: return launchPairR<40, Arith>(a, computeUnits, stream);
+        case 48: return launchPairR<48, Arith>(a, computeUnits, stream);
+        case 56: return launchPairR<56, Arith>(a, computeUnits, stream);
+        case 64: return launchPairR<64, Arith>(a, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// Bytes of LDS the pair table needs for this strip height (host-side sizing).
+static inline size_t pairTableBytes(int rowsPerStrip, int nSymbols) {
+    return (size_t)nSymbols * nSymbols * (size_t)((rowsPerStrip / 4) | 1) * 16;
 }
 
 }  // namespace miopal

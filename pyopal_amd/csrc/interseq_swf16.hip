@@ -7,4 +7,8 @@ hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int wav
     return launchFlavour<ArithSwF16, true>(a, rowsPerStrip, waves, stream);
 }
 
+hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    return launchPairFlavour<ArithSwF16>(a, rowsPerStrip, computeUnits, stream);
+}
+
 }  // namespace miopal

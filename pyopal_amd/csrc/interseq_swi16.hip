@@ -7,4 +7,8 @@ hipError_t launchInterseqSwInt16(const InterseqArgs& a, int rowsPerStrip, int wa
     return launchFlavour<ArithSwI16, true>(a, rowsPerStrip, waves, stream);
 }
 
+hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    return launchPairFlavour<ArithSwI16>(a, rowsPerStrip, computeUnits, stream);
+}
+
 }  // namespace miopal
