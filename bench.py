@@ -128,7 +128,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i16",
+            "dtype": "f16",
             "data": "synthetic",
             "config": {
                 "workload": f"sw_score q{Q} (README.md:86) vs {N}x{L} uniform-random proteins per GPU, "
@@ -144,7 +144,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic(),
-                "traffic_source": "profiles/r01_pmc_interseq_sw_score.json (separate rocprofv3 --pmc passes "
+                "traffic_source": "profiles/r01b_pmc_interseq_pair_kernel.json (separate rocprofv3 --pmc passes "
                                   "FETCH_SIZE x2 + WRITE_SIZE, same kernel and workload)",
                 "kernel": "interseq_pair_kernel<56, ArithSwF16>",
                 "kernel_ms": round(k_ms, 4),
