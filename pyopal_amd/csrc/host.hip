@@ -241,6 +241,9 @@ template <typename T>
 int upload(T* dst, const T* src, size_t n, hipStream_t s) {
     if (n == 0) return 0;
     HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+    // sources are short-lived host vectors: do not rely on the runtime having staged a
+    // large pageable buffer by the time the call returns
+    if (n * sizeof(T) > (1u << 16)) HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 template <typename T>

@@ -67,6 +67,12 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             const bool lastStrip = s + 1 == nStrips;
             uint8_t* dirs = TRACE ? a.dirs + job.dirOff + (size_t)s * nSteps * kLanes : nullptr;
 
+            // per-lane candidate rules, hoisted out of the step loop
+            const bool rowIsLast = i == Q - 1;
+            const bool candAlways = region == kAllCells || (rowIsLast && region != kLastCell);
+            const bool candOnLastCol = region == kLastRowCol || (region == kLastCell && rowIsLast);
+            const bool writer = lane == kLanes - 1 && !lastStrip;
+
             for (int k = 0; k < nSteps; ++k) {
                 if ((k & 63) == 0) {
                     const int kk = k + lane;
@@ -77,9 +83,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                         bF = b.y;
                     }
                 }
-                int hUp = __shfl_up(hCur, 1);
-                int fUp = __shfl_up(fCur, 1);
-                int tin = __shfl_up(tres, 1);
+                // lane 0 takes the row above the strip (border or previous strip), every other
+                // lane what its upper neighbour produced one step earlier: wave_shr:1 keeps
+                // `old` in lane 0, so the select is free
                 const int sel = k & 63;
                 const int t0 = __builtin_amdgcn_readlane(tbuf, sel);
                 int h0, f0;
@@ -90,11 +96,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     h0 = __builtin_amdgcn_readlane(bH, sel);
                     f0 = __builtin_amdgcn_readlane(bF, sel);
                 }
-                if (lane == 0) {
-                    hUp = h0;
-                    fUp = f0;
-                    tin = t0;
-                }
+                const int hUp = __builtin_amdgcn_update_dpp(h0, hCur, 0x138, 0xf, 0xf, false);
+                const int fUp = __builtin_amdgcn_update_dpp(f0, fCur, 0x138, 0xf, 0xf, false);
+                const int tin = __builtin_amdgcn_update_dpp(t0, tres, 0x138, 0xf, 0xf, false);
                 const int j = k - lane;
                 const bool valid = rowActive && j >= 0 && j < L;
                 const int sc = srow[tin];
@@ -113,25 +117,18 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     if (f == fOpen) code |= 8;
                     dirs[(size_t)k * kLanes + lane] = code;
                 }
-                if (valid) {
-                    hDiag = hUp;
-                    hLeft = h;
-                    eLeft = e;
-                    hCur = h;
-                    fCur = f;
-                    tres = tin;
-                    bool cand;
-                    if (region == kAllCells) cand = true;
-                    else if (region == kLastRow) cand = (i == Q - 1);
-                    else if (region == kLastRowCol) cand = (i == Q - 1) || (j == L - 1);
-                    else cand = (i == Q - 1) && (j == L - 1);
-                    if (cand && (h > best || (h == best && j < bj))) {
-                        best = h;
-                        bi = i;
-                        bj = j;
-                    }
-                    if (lane == kLanes - 1 && !lastStrip) bout[j] = make_int2(h, f);
-                }
+                hDiag = valid ? hUp : hDiag;
+                hLeft = valid ? h : hLeft;
+                eLeft = valid ? e : eLeft;
+                hCur = valid ? h : hCur;
+                fCur = valid ? f : fCur;
+                tres = valid ? tin : tres;
+                const bool cand = candAlways || (candOnLastCol && j == L - 1);
+                const bool take = valid && cand && (h > best || (h == best && j < bj));
+                best = take ? h : best;
+                bi = take ? i : bi;
+                bj = take ? j : bj;
+                if (writer && valid) bout[j] = make_int2(h, f);
             }
             if (!lastStrip) __threadfence();
         }

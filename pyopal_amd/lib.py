@@ -720,6 +720,33 @@ class Aligner:
                                 self.gap_extend, self._int_matrix, start, end, device=device)
 
 
+    def scores(self, query, database: BaseDatabase, *, algorithm: str = "sw", start: int = 0,
+               end: int = UINT32_MAX, device: int = 0) -> np.ndarray:
+        """Extension: the scores of ``align(mode="score")`` as
+        one ``int32`` array instead of a list of `ScoreResult` objects, which for a
+        million targets costs more wall time than the search itself."""
+        if algorithm not in _OPAL_ALGORITHMS:
+            raise ValueError(f"invalid algorithm: {algorithm!r}")
+        if database.alphabet != self.alphabet:
+            raise ValueError("database and score matrix have different alphabets")
+        encoded = database.alphabet.encode(query)
+        with database.lock.read:
+            size = database._get_size()
+            if end < start:
+                raise IndexError("database slice end is lower than start")
+            end = min(end, size)
+            if start > size:
+                raise IndexError("database slice start is past the end of the database")
+            if end == start:
+                return np.zeros(0, dtype=np.int32)
+            if _capi.lib().miopalDeviceCount() < 1:
+                raise RuntimeError("no supported SIMD backend available")
+            mirror = database._device_mirror(device)
+            out = mirror.search(np.frombuffer(encoded, dtype=np.uint8), _int_matrix_array(self._int_matrix),
+                                self.gap_open, self.gap_extend, "score", algorithm, start, end)
+            return out["score"]
+
+
 def _int_matrix_array(matrix) -> np.ndarray:
     if isinstance(matrix, array.array):
         return np.frombuffer(matrix, dtype=np.int32)

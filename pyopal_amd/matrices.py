@@ -106,6 +106,34 @@ class ScoringMatrix:
         return cls(rows, _NCBI_ORDER, name=name)
 
     @classmethod
+    def from_file(cls, file, name: typing.Optional[str] = None) -> "ScoringMatrix":
+        """Load a matrix in the NCBI text format (``#`` comments, a header line of
+        column letters, then one row per letter). `file` is a path or a file object."""
+        if isinstance(file, (str, bytes)) or hasattr(file, "__fspath__"):
+            with open(file) as handle:
+                return cls.from_file(handle, name=name)
+        letters = None
+        rows = []
+        row_letters = []
+        for line in file:
+            line = line.strip()
+            if not line or line.startswith("#"):
+                continue
+            fields = line.split()
+            if letters is None:
+                letters = "".join(fields)
+                continue
+            if fields[0].isalpha() or fields[0] == "*":
+                row_letters.append(fields[0])
+                fields = fields[1:]
+            rows.append([float(x) for x in fields])
+        if letters is None:
+            raise ValueError("no matrix found")
+        if row_letters and "".join(row_letters) != letters:
+            raise ValueError("row and column letters differ")
+        return cls(rows, letters, name=name)
+
+    @classmethod
     def from_match_mismatch(cls, match: float = 1.0, mismatch: float = -1.0,
                             alphabet: str = "ACGT") -> "ScoringMatrix":
         n = len(alphabet)

@@ -222,6 +222,22 @@ def test_align_argument_validation():
         list(pyopal.align("ACCTCG", ["AACCGCTG"], 1))
 
 
+def test_scoring_matrix_provider(tmp_path):
+    b62 = ScoringMatrix.from_name("BLOSUM62")
+    assert b62.is_symmetric() and b62.is_integer() and b62.size() == 24
+    assert b62.alphabet == "ARNDCQEGHILKMFPSTWYVBZX*" and (b62.min(), b62.max()) == (-4, 11)
+    text = "# comment\n   " + "  ".join(b62.alphabet) + "\n"
+    for letter, row in zip(b62.alphabet, b62.matrix):
+        text += letter + " " + " ".join(str(int(x)) for x in row) + "\n"
+    path = tmp_path / "m.txt"
+    path.write_text(text)
+    assert ScoringMatrix.from_file(str(path)) == b62
+    assert pickle.loads(pickle.dumps(b62)) == b62
+    dna = ScoringMatrix.from_match_mismatch(5, -4)
+    assert dna.alphabet == "ACGT" and dna[0, 0] == 5 and dna[0, 1] == -4
+    assert pyopal.Aligner(dna).alphabet == "ACGT"
+
+
 def test_public_names():
     # src/pyopal/__init__.py:4-13
     assert sorted(pyopal.__all__) == sorted(

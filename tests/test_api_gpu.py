@@ -93,6 +93,16 @@ def test_slices_and_mirror_invalidation():
     assert [r.score for r in aligner.align(seqs[3], sub)] == [again[0], again[5], again[7]]
 
 
+def test_scores_array_fast_path():
+    rng = np.random.default_rng(4)
+    seqs = ["".join(_data.AA20[i] for i in rng.integers(0, 20, size=int(n))) for n in rng.integers(1, 90, size=64)]
+    db, aligner = pyopal.Database(seqs), pyopal.Aligner()
+    for algo in ("sw", "nw", "hw", "ov"):
+        want = [r.score for r in aligner.align(seqs[0], db, algorithm=algo)]
+        assert aligner.scores(seqs[0], db, algorithm=algo).tolist() == want
+    assert aligner.scores(seqs[0], db, start=10, end=20).tolist() == [r.score for r in aligner.align(seqs[0], db)][10:20]
+
+
 def test_concurrent_queries_share_one_database():
     # README.md:116-144: several threads query one Database through one Aligner
     rng = np.random.default_rng(12)

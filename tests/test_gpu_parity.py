@@ -189,6 +189,28 @@ def test_long_targets_overflow_ladder(capi, algo):
         assert ref["score"].min() < -32768  # really leaves the 16-bit range
 
 
+@pytest.mark.parametrize("A", [4, 20, 32])
+def test_other_alphabets(capi, A):
+    # alphabets from 4 letters to the 32-letter maximum (src/pyopal/lib.pxd:28-32),
+    # asymmetric matrix on purpose: rows are indexed by the QUERY residue
+    rng = np.random.default_rng(A)
+    matrix = rng.integers(-6, 8, size=(A, A)).astype(np.int32)
+    matrix[np.arange(A), np.arange(A)] = rng.integers(3, 12, size=A)
+    seqs = [rng.integers(0, A, size=int(n)).astype(np.uint8) for n in rng.integers(1, 260, size=300)]
+    res, off = _oracle.flatten(seqs)
+    for qlen in (37, 150):
+        q = rng.integers(0, A, size=qlen).astype(np.uint8)
+        for algo in ALGOS:
+            db = capi.DeviceDatabase(res, off, A)
+            try:
+                for mode in ("score", "full"):
+                    gpu = db.search(q, matrix.ravel(), 5, 2, mode, algo)
+                    ref = _oracle.search(q, res, off, matrix.ravel(), 5, 2, mode, algo)
+                    compare(gpu, ref, mode, f"A={A} {algo} {mode} Q={qlen}")
+            finally:
+                db.close()
+
+
 def test_opal_search_database_entry(capi):
     """The literal opal.h entry point (host pointers in, result structs out)."""
     import ctypes
