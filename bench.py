@@ -158,10 +158,42 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(query, residues, offsets, matrix, Q, N, L, got)
+            line["extras"] = extras(db, query, matrix, Q, N, L)
         print(json.dumps(line), flush=True)
     db.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def extras(db, query, matrix, Q, N, L):
+    """Secondary measurements asked for by SURVEY.md section 8d; never part of `value`."""
+    import _data
+    from pyopal_amd import _capi
+    out = {}
+    # (a) the host-buffer form of the same search: miopalSearch incl. the 4 MB D2H and sync
+    db.search(query, matrix, 3, 1, "score", "sw")
+    t0 = time.perf_counter()
+    for _ in range(5):
+        db.search(query, matrix, 3, 1, "score", "sw")
+    dt = (time.perf_counter() - t0) / 5
+    out["host_results_ms_per_search"] = round(dt * 1e3, 3)
+    out["host_results_gcups"] = round(float(Q) * N * L / dt / 1e9, 1)
+    # (b) lane-packing efficiency on UniProt-like lengths (log-normal, mean about 300)
+    rng = np.random.default_rng(7)
+    n = min(N, 500_000)
+    lengths = np.clip(rng.lognormal(mean=5.55, sigma=0.6, size=n), 20, 8000).astype(np.int64)
+    res, off = _data.random_db(rng, lengths)
+    vdb = _capi.DeviceDatabase(res, off, 24, device=db.device)
+    vdb.search(query, matrix, 3, 1, "score", "sw")
+    t0 = time.perf_counter()
+    for _ in range(5):
+        vdb.search(query, matrix, 3, 1, "score", "sw")
+    dt = (time.perf_counter() - t0) / 5
+    vdb.close()
+    out["lognormal_lengths"] = {"targets": int(n), "mean_length": round(float(lengths.mean()), 1),
+                                "max_length": int(lengths.max()),
+                                "host_results_gcups": round(float(Q) * float(lengths.sum()) / dt / 1e9, 1)}
+    return out
 
 
 def pmc_traffic():

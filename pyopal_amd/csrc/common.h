@@ -35,6 +35,8 @@ struct InterseqArgs {
     int region;                // Region: where the answer is taken
     const int32_t* lens;       // [nGroups * 128] target lengths, packed-view order (0 = absent)
     int32_t* score;            // [nGroups * 128], packed-view order
+    int32_t* endI;             // LOC kernels: query coordinate of the answer (-1 = none)
+    int32_t* endJ;             // LOC kernels: target coordinate
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
@@ -103,7 +105,7 @@ enum InterseqFlavour : int {
     kSignedInt16AllCells = 3  // anchored reverse pass: signed, every cell is a candidate
 };
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
-                          hipStream_t stream);
+                          bool locate, hipStream_t stream);
 // pair-indexed LDS profile (single strip, Smith-Waterman); false = table does not fit LDS
 bool interseqPairFits(int rowsPerStrip, int nSymbols);
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, int computeUnits,
@@ -111,15 +113,22 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool half
 hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSwHalfLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSwInt16(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSwInt16Loc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSigned(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSignedLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,
                          hipStream_t stream);
+hipError_t launchScatterEnds(const int32_t* viewEndI, const int32_t* viewEndJ, const int32_t* ids,
+                             int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ,
+                             hipStream_t stream);
 
 inline int packRules(const DpRules& r) {
     return (r.topGap ? 1 : 0) | (r.leftGap ? 2 : 0) | (r.floor0 ? 4 : 0) | (r.region << 4);

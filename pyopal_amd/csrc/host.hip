@@ -85,7 +85,7 @@ constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent st
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kSlots
 };
 
 struct Workspace {
@@ -396,7 +396,7 @@ struct Search {
     }
 
     bool interseqUsable() const {
-        if (searchType != OPAL_SEARCH_SCORE || Q <= 0) return false;
+        if (Q <= 0) return false;
         if (open < 0 || ext < 0) return false;
         if (maxScore > 16383 || minScore < -16383) return false;
         return true;
@@ -540,6 +540,14 @@ struct Search {
             ia.region = r.region;
             ia.lens = view->d_lens;
             ia.score = (int32_t*)vs;
+            const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
+            if (locate) {
+                void *vi, *vj;
+                RC_TRY(ws->get(kViewEndI, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vi));
+                RC_TRY(ws->get(kViewEndJ, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vj));
+                ia.endI = (int32_t*)vi;
+                ia.endJ = (int32_t*)vj;
+            }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.boundaryOff = view->d_boundaryOff;
             // strips of a group in flight (wavefronts per workgroup)
@@ -561,7 +569,7 @@ struct Search {
             }
             // one strip + Smith-Waterman: the pair-indexed LDS profile saves the v_perm per cell
             const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
-            if (sw && nStrips == 1 && !(noPair && noPair[0] == '1') && interseqPairFits(rows, nSym)) {
+            if (sw && !locate && nStrips == 1 && !(noPair && noPair[0] == '1') && interseqPairFits(rows, nSym)) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
@@ -569,7 +577,7 @@ struct Search {
                 HIP_TRY(launchInterseqPair(ia, rows, halfFloat, db->computeUnits, stream));
             }
             else
-                HIP_TRY(launchInterseq(ia, rows, waves, flavour, stream));
+                HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
             if (timed) {
                 HIP_TRY(hipEventRecord(e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
@@ -578,6 +586,9 @@ struct Search {
             }
             HIP_TRY(launchScatter(ia.score, (const uint8_t*)vo, view->d_ids, view->nPacked, start, d_score,
                                   mayOverflow ? (int32_t*)ct : nullptr, stream));
+            if (locate)
+                HIP_TRY(launchScatterEnds(ia.endI, ia.endJ, view->d_ids, view->nPacked, start, d_endI, d_endJ,
+                                          stream));
             if (mayOverflow) {
                 int32_t count = 0;
                 RC_TRY(download(&count, (const int32_t*)ct, 1, stream));

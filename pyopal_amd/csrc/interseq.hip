@@ -4,8 +4,17 @@
 namespace miopal {
 
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
-                          hipStream_t stream) {
+                          bool locate, hipStream_t stream) {
     if (a.nGroups <= 0) return hipSuccess;
+    if (locate) {
+        switch (flavour) {
+            case kSwHalf: return launchInterseqSwHalfLoc(a, rowsPerStrip, waves, stream);
+            case kSwInt16: return launchInterseqSwInt16Loc(a, rowsPerStrip, waves, stream);
+            case kSignedInt16: return launchInterseqSignedLoc(a, rowsPerStrip, waves, stream);
+            case kSignedInt16AllCells: return launchInterseqSignedAllLoc(a, rowsPerStrip, waves, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (flavour) {
         case kSwHalf: return launchInterseqSwHalf(a, rowsPerStrip, waves, stream);
         case kSwInt16: return launchInterseqSwInt16(a, rowsPerStrip, waves, stream);

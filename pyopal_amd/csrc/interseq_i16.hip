@@ -4,7 +4,7 @@
 namespace miopal {
 
 hipError_t launchInterseqSigned(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
-    return launchFlavour<ArithI16, false>(a, rowsPerStrip, waves, stream);
+    return launchFlavour<ArithI16, false, false>(a, rowsPerStrip, waves, stream);
 }
 
 }  // namespace miopal

@@ -4,7 +4,7 @@
 namespace miopal {
 
 hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
-    return launchFlavour<ArithI16, true>(a, rowsPerStrip, waves, stream);
+    return launchFlavour<ArithI16, true, false>(a, rowsPerStrip, waves, stream);
 }
 
 }  // namespace miopal

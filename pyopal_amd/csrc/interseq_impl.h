@@ -164,10 +164,14 @@ static __device__ __forceinline__ uint32_t selectHalves(uint32_t dst, uint32_t v
 }
 
 // MULTI = false: the query fits one strip (no boundary traffic, no rounds).
-template <int R, typename Arith, int W, bool TRACK_ALL, bool MULTI>
+// LOC = true: also report where the answer was found (OPAL_SEARCH_SCORE_END): the
+// first maximum when candidates are visited target column by target column and,
+// inside a column, query row by query row (oracle/opal_oracle.c).
+template <int R, typename Arith, int W, bool TRACK_ALL, bool MULTI, bool LOC>
 __global__ __launch_bounds__(W * kLanes)
 void interseq_kernel(InterseqArgs a) {
     static_assert(MULTI || W == 1, "a single strip needs a single wavefront");
+    constexpr int kLowInt = Arith::kFloor ? 0 : INT32_MIN;
     constexpr bool kRegions = !Arith::kFloor;  // Smith-Waterman flavours only know the all-cells maximum
     constexpr int SLOTS = ProfileLayout<R>::kSlots;
     constexpr int NB = R / 8;
@@ -175,6 +179,7 @@ void interseq_kernel(InterseqArgs a) {
     __shared__ uint4 ldsProf[W][(kMaxAlphabet + 1) * SLOTS];
     __shared__ uint2 ldsBnd[WB][2][W > 1 ? 4 * kLanes : 1];
     __shared__ uint32_t ldsOut[WB][W > 1 ? kLanes : 1];
+    __shared__ int ldsLoc[(LOC && W > 1) ? W : 1][(LOC && W > 1) ? 10 : 1][(LOC && W > 1) ? kLanes : 1];
 
     const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
@@ -195,7 +200,7 @@ void interseq_kernel(InterseqArgs a) {
     // per-lane target lengths (NW / OV take answers at each target's own last column)
     const size_t base = (size_t)g * kGroupTargets;
     int lenA = 0, lenB = 0;
-    if (kRegions && (!TRACK_ALL || region != kAllCells)) {
+    if (LOC || (kRegions && (!TRACK_ALL || region != kAllCells))) {
         lenA = a.lens[base + lane];
         lenB = a.lens[base + kLanes + lane];
     }
@@ -203,6 +208,13 @@ void interseq_kernel(InterseqArgs a) {
     uint32_t best = Arith::lowest(), held = Arith::lowest();  // maximum over all cells (TRACK_ALL)
     uint32_t ans = Arith::lowest();                            // answer of the other regions
     uint32_t H[R], E[R];
+    // LOC state, one set per packed half (A = low, B = high): running best score with
+    // its column / row, the same for the strip in flight (all-cells region), and the
+    // last-column candidate of OV
+    int runA = kLowInt, runB = kLowInt, colA = -1, colB = -1, rowA = -1, rowB = -1;
+    int scolA = -1, scolB = -1, srowA = -1, srowB = -1;
+    int cbA = kLowInt, cbB = kLowInt, crowA = -1, crowB = -1;
+    uint32_t bestPrev = Arith::lowest();
 
     const int lastStrip = nStrips - 1;
     const int rl = Q - 1 - lastStrip * R;  // row of the last query residue inside the last strip
@@ -352,8 +364,67 @@ void interseq_kernel(InterseqArgs a) {
                         b2 = b3;
                     }
 
+                    if constexpr (LOC && TRACK_ALL) {
+                        // a half of `best` that changed in this column holds a new strict
+                        // maximum: its row is the first row of the column with that value
+                        const uint32_t ch = best ^ bestPrev;
+                        if (region == kAllCells && __builtin_amdgcn_ballot_w64(ch != 0) != 0) {
+                            const uint32_t nbA = best & 0xffffu, nbB = best >> 16;
+                            int ra = 0, rb = 0;
+#pragma unroll
+                            for (int r = R - 1; r >= 0; --r) {
+                                if ((H[r] & 0xffffu) == nbA) ra = r;
+                                if ((H[r] >> 16) == nbB) rb = r;
+                            }
+                            if (ch & 0xffffu) {
+                                scolA = j;
+                                srowA = s * R + ra;
+                            }
+                            if (ch >> 16) {
+                                scolB = j;
+                                srowB = s * R + rb;
+                            }
+                            bestPrev = best;
+                        }
+                    }
+                    if constexpr (LOC && kRegions) {
+                        if (region != kAllCells) {
+                            const uint32_t lastMask = ((j == lenA - 1) ? 0x0000ffffu : 0u) |
+                                                      ((j == lenB - 1) ? 0xffff0000u : 0u);
+                            if (isLast) {
+                                uint32_t hq = H[0];
+#pragma unroll
+                                for (int r = 1; r < R; ++r)
+                                    if (r == rl) hq = H[r];
+                                const int qA = Arith::toInt(hq & 0xffffu), qB = Arith::toInt(hq >> 16);
+                                if (region == kLastCell) {
+                                    if (j == lenA - 1) { runA = qA; colA = j; }
+                                    if (j == lenB - 1) { runB = qB; colB = j; }
+                                } else {
+                                    // last row: HW scans columns < len, OV columns < len - 1 (its
+                                    // last column is scanned row by row below)
+                                    const int cut = region == kLastRowCol ? 1 : 0;
+                                    if (j < lenA - cut && qA > runA) { runA = qA; colA = j; }
+                                    if (j < lenB - cut && qB > runB) { runB = qB; colB = j; }
+                                }
+                            }
+                            if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastMask != 0) != 0) {
+                                int mA = INT32_MIN, mB = INT32_MIN, ra = 0, rb = 0;
+#pragma unroll
+                                for (int r = R - 1; r >= 0; --r) {
+                                    if (s * R + r < Q) {
+                                        const int hA = Arith::toInt(H[r] & 0xffffu), hB = Arith::toInt(H[r] >> 16);
+                                        if (hA >= mA) { mA = hA; ra = r; }
+                                        if (hB >= mB) { mB = hB; rb = r; }
+                                    }
+                                }
+                                if ((lastMask & 0xffffu) && mA > cbA) { cbA = mA; crowA = s * R + ra; }
+                                if ((lastMask >> 16) && mB > cbB) { cbB = mB; crowB = s * R + rb; }
+                            }
+                        }
+                    }
                     // ---- answers on the last query row / each target's last column ----
-                    if (kRegions && (!TRACK_ALL || region != kAllCells)) {
+                    if (!LOC && kRegions && (!TRACK_ALL || region != kAllCells)) {
                         const uint32_t lastMask = ((j == lenA - 1) ? 0x0000ffffu : 0u) |
                                                   ((j == lenB - 1) ? 0xffff0000u : 0u);
                         if (isLast) {
@@ -377,6 +448,19 @@ void interseq_kernel(InterseqArgs a) {
             }
             if (W > 1) __syncthreads();
         }
+        if constexpr (LOC && TRACK_ALL) {
+            if (region == kAllCells && active) {
+                // fold this strip's first maximum into the running one: higher score wins,
+                // then the smaller column (rows of later strips are larger)
+                const int sA = Arith::toInt(best & 0xffffu), sB = Arith::toInt(best >> 16);
+                if (scolA >= 0 && (sA > runA || (sA == runA && scolA < colA))) { runA = sA; colA = scolA; rowA = srowA; }
+                if (scolB >= 0 && (sB > runB || (sB == runB && scolB < colB))) { runB = sB; colB = scolB; rowB = srowB; }
+                best = Arith::lowest();
+                held = Arith::lowest();
+                bestPrev = Arith::lowest();
+                scolA = scolB = srowA = srowB = -1;
+            }
+        }
         if (MULTI && nRounds > 1) {
             // the next round's first strip reads what this round's last strip wrote to HBM
             __threadfence();
@@ -385,6 +469,59 @@ void interseq_kernel(InterseqArgs a) {
     }
 
     // ---- combine the wavefronts' partial answers ---------------------------------
+    if constexpr (LOC) {
+        if (W > 1) {
+            ldsLoc[wave][0][lane] = runA;
+            ldsLoc[wave][1][lane] = runB;
+            ldsLoc[wave][2][lane] = colA;
+            ldsLoc[wave][3][lane] = colB;
+            ldsLoc[wave][4][lane] = rowA;
+            ldsLoc[wave][5][lane] = rowB;
+            ldsLoc[wave][6][lane] = cbA;
+            ldsLoc[wave][7][lane] = cbB;
+            ldsLoc[wave][8][lane] = crowA;
+            ldsLoc[wave][9][lane] = crowB;
+            __syncthreads();
+            if (wave != 0) return;
+            for (int w = 1; w < W; ++w) {
+                const int oA = ldsLoc[w][0][lane], oB = ldsLoc[w][1][lane];
+                const int ocA = ldsLoc[w][2][lane], ocB = ldsLoc[w][3][lane];
+                const int orA = ldsLoc[w][4][lane], orB = ldsLoc[w][5][lane];
+                // same order as the scan: score, then column, then row
+                if (ocA >= 0 && (colA < 0 || oA > runA || (oA == runA && (ocA < colA || (ocA == colA && orA < rowA))))) {
+                    runA = oA; colA = ocA; rowA = orA;
+                }
+                if (ocB >= 0 && (colB < 0 || oB > runB || (oB == runB && (ocB < colB || (ocB == colB && orB < rowB))))) {
+                    runB = oB; colB = ocB; rowB = orB;
+                }
+                const int pA = ldsLoc[w][6][lane], pB = ldsLoc[w][7][lane];
+                const int prA = ldsLoc[w][8][lane], prB = ldsLoc[w][9][lane];
+                if (prA >= 0 && (crowA < 0 || pA > cbA || (pA == cbA && prA < crowA))) { cbA = pA; crowA = prA; }
+                if (prB >= 0 && (crowB < 0 || pB > cbB || (pB == cbB && prB < crowB))) { cbB = pB; crowB = prB; }
+            }
+        }
+        if (region != kAllCells) {
+            // answers of the last-row regions sit on query row Q - 1
+            rowA = colA >= 0 ? Q - 1 : -1;
+            rowB = colB >= 0 ? Q - 1 : -1;
+        }
+        if (region == kLastRowCol) {
+            // OV: the last column is scanned after the last row, strictly greater wins
+            if (crowA >= 0 && (colA < 0 || cbA > runA)) { runA = cbA; rowA = crowA; colA = lenA - 1; }
+            if (crowB >= 0 && (colB < 0 || cbB > runB)) { runB = cbB; rowB = crowB; colB = lenB - 1; }
+        }
+        a.score[base + lane] = runA;
+        a.score[base + kLanes + lane] = runB;
+        a.endI[base + lane] = rowA;
+        a.endI[base + kLanes + lane] = rowB;
+        a.endJ[base + lane] = colA;
+        a.endJ[base + kLanes + lane] = colB;
+        if (a.overflow) {
+            a.overflow[base + lane] = runA >= Arith::kLimit;
+            a.overflow[base + kLanes + lane] = runB >= Arith::kLimit;
+        }
+        return;
+    }
     uint32_t res = (TRACK_ALL && region == kAllCells) ? best : ans;
     if (W > 1) {
         ldsOut[wave][lane] = res;
@@ -401,18 +538,18 @@ void interseq_kernel(InterseqArgs a) {
     }
 }
 
-template <int R, typename Arith, bool TRACK_ALL>
+template <int R, typename Arith, bool TRACK_ALL, bool LOC>
 static hipError_t launchW(const InterseqArgs& a, int waves, hipStream_t stream) {
     const dim3 grid(a.nGroups);
     if (a.nStrips == 1) {
-        hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, false>), grid, dim3(kLanes), 0, stream, a);
+        hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, false, LOC>), grid, dim3(kLanes), 0, stream, a);
         return hipGetLastError();
     }
     switch (waves) {
-        case 1: hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, true>), grid, dim3(1 * kLanes), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((interseq_kernel<R, Arith, 2, TRACK_ALL, true>), grid, dim3(2 * kLanes), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((interseq_kernel<R, Arith, 4, TRACK_ALL, true>), grid, dim3(4 * kLanes), 0, stream, a); break;
-        case 8: hipLaunchKernelGGL((interseq_kernel<R, Arith, 8, TRACK_ALL, true>), grid, dim3(8 * kLanes), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, true, LOC>), grid, dim3(1 * kLanes), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((interseq_kernel<R, Arith, 2, TRACK_ALL, true, LOC>), grid, dim3(2 * kLanes), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((interseq_kernel<R, Arith, 4, TRACK_ALL, true, LOC>), grid, dim3(4 * kLanes), 0, stream, a); break;
+        case 8: hipLaunchKernelGGL((interseq_kernel<R, Arith, 8, TRACK_ALL, true, LOC>), grid, dim3(8 * kLanes), 0, stream, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -420,17 +557,17 @@ static hipError_t launchW(const InterseqArgs& a, int waves, hipStream_t stream) 
 
 // Rows per strip are a multiple of 8 (one ds_read_b128 = 8 16-bit scores);
 // `waves` (1, 2, 4 or 8) is the number of strips of a group in flight.
-template <typename Arith, bool TRACK_ALL>
+template <typename Arith, bool TRACK_ALL, bool LOC>
 static hipError_t launchFlavour(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
     switch (rowsPerStrip) {
-        case 8: return launchW<8, Arith, TRACK_ALL>(a, waves, stream);
-        case 16: return launchW<16, Arith, TRACK_ALL>(a, waves, stream);
-        case 24: return launchW<24, Arith, TRACK_ALL>(a, waves, stream);
-        case 32: return launchW<32, Arith, TRACK_ALL>(a, waves, stream);
-        case 40: return launchW<40, Arith, TRACK_ALL>(a, waves, stream);
-        case 48: return launchW<48, Arith, TRACK_ALL>(a, waves, stream);
-        case 56: return launchW<56, Arith, TRACK_ALL>(a, waves, stream);
-        case 64: return launchW<64, Arith, TRACK_ALL>(a, waves, stream);
+        case 8: return launchW<8, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 16: return launchW<16, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 24: return launchW<24, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 32: return launchW<32, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 40: return launchW<40, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 48: return launchW<48, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 56: return launchW<56, Arith, TRACK_ALL, LOC>(a, waves, stream);
+        case 64: return launchW<64, Arith, TRACK_ALL, LOC>(a, waves, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -4,7 +4,7 @@
 namespace miopal {
 
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
-    return launchFlavour<ArithSwF16, true>(a, rowsPerStrip, waves, stream);
+    return launchFlavour<ArithSwF16, true, false>(a, rowsPerStrip, waves, stream);
 }
 
 hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {

@@ -4,7 +4,7 @@
 namespace miopal {
 
 hipError_t launchInterseqSwInt16(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
-    return launchFlavour<ArithSwI16, true>(a, rowsPerStrip, waves, stream);
+    return launchFlavour<ArithSwI16, true, false>(a, rowsPerStrip, waves, stream);
 }
 
 hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {

@@ -1,0 +1,10 @@
+// One arithmetic flavour of the inter-sequence kernel, with end locations (interseq_impl.h).
+#include "interseq_impl.h"
+
+namespace miopal {
+
+hipError_t launchInterseqSwInt16Loc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream) {
+    return launchFlavour<ArithSwI16, true, true>(a, rowsPerStrip, waves, stream);
+}
+
+}  // namespace miopal

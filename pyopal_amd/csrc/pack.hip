@@ -73,6 +73,25 @@ __global__ void scatter_kernel(const int32_t* viewScore, const uint8_t* viewOver
     if (overflowCount != nullptr && viewOverflow[k]) atomicAdd(overflowCount, 1);
 }
 
+__global__ void scatter_ends_kernel(const int32_t* viewEndI, const int32_t* viewEndJ, const int32_t* ids,
+                                    int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nTargets) return;
+    const int64_t slot = ids[k] - sliceStart;
+    outI[slot] = viewEndI[k];
+    outJ[slot] = viewEndJ[k];
+}
+
+hipError_t launchScatterEnds(const int32_t* viewEndI, const int32_t* viewEndJ, const int32_t* ids,
+                             int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ,
+                             hipStream_t stream) {
+    if (nTargets <= 0) return hipSuccess;
+    const int threads = 256;
+    hipLaunchKernelGGL(scatter_ends_kernel, dim3((nTargets + threads - 1) / threads), dim3(threads), 0, stream,
+                       viewEndI, viewEndJ, ids, nTargets, sliceStart, outI, outJ);
+    return hipGetLastError();
+}
+
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream) {
     const int64_t n = totalChunks * kLanes;
     if (n <= 0) return hipSuccess;
