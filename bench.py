@@ -199,7 +199,7 @@ def extras(db, query, matrix, Q, N, L):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary
     (counters cannot be collected from inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_interseq_sw_score.json")
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_interseq_pair_kernel.json")
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_traffic_bytes_per_launch"])

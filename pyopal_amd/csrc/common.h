@@ -38,6 +38,7 @@ struct InterseqArgs {
     int32_t* endI;             // LOC kernels: query coordinate of the answer (-1 = none)
     int32_t* endJ;             // LOC kernels: target coordinate
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
+    int priorityChunks;        // groups with more chunks than this raise their wave priority
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;

@@ -84,7 +84,7 @@ constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent st
 // ---------------------------------------------------------------------------
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
-    kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
+    kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
     kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kSlots
 };
 
@@ -95,6 +95,17 @@ struct Workspace {
     size_t cap[kSlots] = {};
     std::mutex busy;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timings;  // dominant-kernel launches
+    // side stream for the intra-sequence recompute that runs beside the inter-sequence kernel
+    hipStream_t aux = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+
+    int ensureAux() {
+        if (aux) return 0;
+        HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
+        return 0;
+    }
 
     int get(int slot, size_t bytes, void** out) {
         if (bytes == 0) bytes = 16;
@@ -124,6 +135,9 @@ struct Workspace {
         }
         for (void* p : buf)
             if (p) (void)hipFree(p);
+        if (evFork) (void)hipEventDestroy(evFork);
+        if (evJoin) (void)hipEventDestroy(evJoin);
+        if (aux) (void)hipStreamDestroy(aux);
         if (ownsStream && stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -136,6 +150,7 @@ struct View {
     int nPacked = 0;                 // targets in the packed groups
     int nGroups = 0;
     int maxPackedLen = 0;
+    int64_t balancedCols = 0;        // columns a wavefront slot gets when the view is spread evenly
     int64_t totalChunks = 0;
     std::vector<int32_t> ids;        // view position -> database index (packed part)
     std::vector<int32_t> longIds;    // targets always handled by the intra-sequence kernel
@@ -269,6 +284,24 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
     // longest first: the heaviest wavefronts are dispatched first
     std::stable_sort(ids.begin(), ids.end(),
                      [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
+    // A group keeps one wavefront busy for as many columns as its longest target has.
+    // Groups far above the balanced share of a wavefront slot would stretch the kernel to
+    // their own length (one lane per target cannot split a target), so their targets go to
+    // the intra-sequence kernel, which spreads each pair over 64 lanes.
+    {
+        int64_t totalCols = 0;
+        for (size_t k = 0; k < ids.size(); k += kGroupTargets) totalCols += dbLen(db, ids[k]);
+        const int64_t slots = (int64_t)db->computeUnits * 12;
+        v->balancedCols = totalCols / std::max<int64_t>(slots, 1);
+        const int64_t limit = std::max<int64_t>(5 * v->balancedCols / 2, 512);
+        size_t cut = 0;
+        while (cut < ids.size() && dbLen(db, ids[cut]) > limit) cut += kGroupTargets;
+        cut = std::min(cut, ids.size());
+        if (cut > 0) {
+            v->longIds.insert(v->longIds.end(), ids.begin(), ids.begin() + (ptrdiff_t)cut);
+            ids.erase(ids.begin(), ids.begin() + (ptrdiff_t)cut);
+        }
+    }
     v->nPacked = (int)ids.size();
     v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
     std::vector<int64_t> groupOff(v->nGroups + 1, 0), chunkPrefix(v->nGroups + 1, 0), boundaryOff(v->nGroups + 1, 0);
@@ -404,8 +437,9 @@ struct Search {
 
     // Runs the intra-sequence kernel over `jobs`; results land in the given device arrays.
     int runPairs(std::vector<PairJob>& jobs, bool trace, int32_t* d_score, int32_t* d_endI,
-                 int32_t* d_endJ, uint8_t* d_dirs) {
+                 int32_t* d_endJ, uint8_t* d_dirs, hipStream_t on = nullptr, int slotBase = 0) {
         if (jobs.empty()) return 0;
+        if (!on) on = stream;
         RC_TRY(ensurePairInputs());
         int64_t wsElems = 0;
         for (auto& j : jobs) {
@@ -413,10 +447,11 @@ struct Search {
             if (j.qLen > kLanes) wsElems += j.tLen;
         }
         void *pj, *b0, *b1;
-        RC_TRY(ws->get(kJobs, jobs.size() * sizeof(PairJob), &pj));
-        RC_TRY(ws->get(kPairB0, (size_t)wsElems * sizeof(int2), &b0));
-        RC_TRY(ws->get(kPairB1, (size_t)wsElems * sizeof(int2), &b1));
-        RC_TRY(upload((PairJob*)pj, jobs.data(), jobs.size(), stream));
+        // the side stream has its own job / boundary buffers (slotBase = kAuxJobs - kJobs)
+        RC_TRY(ws->get(kJobs + slotBase, jobs.size() * sizeof(PairJob), &pj));
+        RC_TRY(ws->get(kPairB0 + slotBase, (size_t)wsElems * sizeof(int2), &b0));
+        RC_TRY(ws->get(kPairB1 + slotBase, (size_t)wsElems * sizeof(int2), &b1));
+        RC_TRY(upload((PairJob*)pj, jobs.data(), jobs.size(), on));
         IntraseqArgs a{};
         a.jobs = (const PairJob*)pj;
         a.nJobs = (int)jobs.size();
@@ -432,7 +467,7 @@ struct Search {
         a.score = d_score;
         a.endI = d_endI;
         a.endJ = d_endJ;
-        HIP_TRY(launchIntraseq(a, trace, stream));
+        HIP_TRY(launchIntraseq(a, trace, on));
         return 0;
     }
 
@@ -469,7 +504,9 @@ struct Search {
 
         std::shared_ptr<View> view;
         RC_TRY(getView(db, start, end, &view));
-        for (int32_t id : view->longIds) jobs.push_back(forwardJob(id, rules));
+        // not in the packed view: can be recomputed beside the packed kernel
+        std::vector<PairJob> sideJobs;
+        for (int32_t id : view->longIds) sideJobs.push_back(forwardJob(id, rules));
 
         if (view->nGroups > 0) {
             const int nStrips = (Q + kMaxStripRows - 1) / kMaxStripRows;
@@ -512,6 +549,20 @@ struct Search {
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
                 for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t]);
+            // targets kept out of the packed view (too long for one lane each) are computed by the
+            // int32 kernel on a side stream BESIDE the packed kernel; packed targets that need
+            // the int32 kernel are redone after it, because both write the same result slots
+            bool forked = false;
+            if (!sideJobs.empty()) {
+                RC_TRY(ws->ensureAux());
+                RC_TRY(ensurePairInputs());
+                HIP_TRY(hipEventRecord(ws->evFork, stream));
+                HIP_TRY(hipStreamWaitEvent(ws->aux, ws->evFork, 0));
+                RC_TRY(runPairs(sideJobs, false, d_score, d_endI, d_endJ, nullptr, ws->aux, kAuxJobs - kJobs));
+                HIP_TRY(hipEventRecord(ws->evJoin, ws->aux));
+                sideJobs.clear();
+                forked = true;
+            }
             void *pp, *vs, *vo, *ct;
             RC_TRY(ws->get(kProfile, prof.size() * sizeof(int16_t), &pp));
             RC_TRY(ws->get(kViewScore, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vs));
@@ -550,6 +601,7 @@ struct Search {
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.boundaryOff = view->d_boundaryOff;
+            ia.priorityChunks = (int)std::min<int64_t>(std::max<int64_t>(view->balancedCols / 4, 16), INT32_MAX);
             // strips of a group in flight (wavefronts per workgroup)
             const int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
             if ((nStrips + waves - 1) / waves > 1) {
@@ -589,6 +641,7 @@ struct Search {
             if (locate)
                 HIP_TRY(launchScatterEnds(ia.endI, ia.endJ, view->d_ids, view->nPacked, start, d_endI, d_endJ,
                                           stream));
+            if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws->evJoin, 0));
             if (mayOverflow) {
                 int32_t count = 0;
                 RC_TRY(download(&count, (const int32_t*)ct, 1, stream));
@@ -607,6 +660,7 @@ struct Search {
                 }
             }
         }
+        jobs.insert(jobs.end(), sideJobs.begin(), sideJobs.end());
         return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
     }
 };

@@ -188,6 +188,7 @@ void interseq_kernel(InterseqArgs a) {
     uint4* prof = ldsProf[wave];
     const uint2* pack = a.pack + a.groupOff[g];
     const int nChunks = a.groupChunks[g];
+    if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);  // long group: critical path
     const Arith ar(a.gapOpen, a.gapExt);
     const uint4* gprof = reinterpret_cast<const uint4*>(a.profile);
     const int rowSlotsGlobal = a.qPad / 8;
@@ -618,14 +619,34 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_kernel(Inte
     }
     __syncthreads();
 
-    // groups are handed out dynamically (longest first), so wavefronts finish together
+    // Hand-out of groups (sorted longest first). First round: static and striped, so that
+    // every CU, and every SIMD inside it (wavefronts w, w+4, w+8 share one), starts with
+    // a mix of long and short groups: wavefront w takes tier kTier[w % 4][w / 4] of
+    // gridDim.x groups each, in snake order across workgroups. Later rounds: whoever
+    // finishes pulls the next group from a shared counter, so wavefronts finish together.
+    const int wave = threadIdx.x >> 6;
+    constexpr int kTier[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
+    const int tier = kTier[wave & 3][wave >> 2];
+    const int firstDynamic = kPairWaves * gridDim.x;
+    bool firstRound = true;
     for (;;) {
-        int g = 0;
-        if (lane == 0) g = atomicAdd(a.workCounter, 1);
-        g = __builtin_amdgcn_readfirstlane(g);
-        if (g >= a.nGroups) break;
+        int g;
+        if (firstRound) {
+            g = tier * gridDim.x + ((tier & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x);
+            firstRound = false;
+            if (g >= a.nGroups) continue;
+        } else {
+            g = 0;
+            if (lane == 0) g = atomicAdd(a.workCounter, 1);
+            g = __builtin_amdgcn_readfirstlane(g) + firstDynamic;
+            if (g >= a.nGroups) break;
+        }
         const uint2* pack = a.pack + a.groupOff[g];
         const int nChunks = a.groupChunks[g];
+        // a group much longer than a wavefront's balanced share is on the critical path:
+        // let it win the SIMD's issue arbitration against its co-resident wavefronts
+        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
         uint32_t best = 0u, held = 0u;
         uint32_t H[R], E[R];
 #pragma unroll
