@@ -24,7 +24,8 @@ struct InterseqArgs {
     const uint2* pack;         // [group][chunk][lane] -> {4 residues of A, 4 residues of B}
     const int64_t* groupOff;   // first uint2 of each group
     const int* groupChunks;    // 4-column chunks per group
-    int nGroups;
+    int nGroups;               // groups to process, starting at groupBase
+    int groupBase;             // leading (longest) groups skipped by this launch
     const int16_t* profile;    // [A+1][Qpad] substitution scores, row A = padding symbol
     int nSymbols;              // A + 1
     int qPad;                  // nStrips * R
@@ -103,7 +104,8 @@ enum InterseqFlavour : int {
     kSwHalf = 0,              // Smith-Waterman, packed half floats (exact below 2048)
     kSwInt16 = 1,             // Smith-Waterman, saturating int16
     kSignedInt16 = 2,         // NW / HW / OV, signed saturating int16
-    kSignedInt16AllCells = 3  // anchored reverse pass: signed, every cell is a candidate
+    kSignedInt16AllCells = 3, // anchored reverse pass: signed, every cell is a candidate
+    kSignedInt16Diag = 4      // NW / HW / OV on anti-diagonally shifted values (6 ops per cell pair)
 };
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
                           bool locate, hipStream_t stream);
@@ -120,6 +122,8 @@ hipError_t launchInterseqSwInt16Loc(const InterseqArgs& a, int rowsPerStrip, int
 hipError_t launchInterseqSigned(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSignedDiag(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);

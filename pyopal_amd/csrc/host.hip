@@ -150,7 +150,7 @@ struct View {
     int nPacked = 0;                 // targets in the packed groups
     int nGroups = 0;
     int maxPackedLen = 0;
-    int64_t balancedCols = 0;        // columns a wavefront slot gets when the view is spread evenly
+    std::vector<int> groupChunksHost;  // 4-column chunks per group (longest group first)
     int64_t totalChunks = 0;
     std::vector<int32_t> ids;        // view position -> database index (packed part)
     std::vector<int32_t> longIds;    // targets always handled by the intra-sequence kernel
@@ -284,24 +284,6 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
     // longest first: the heaviest wavefronts are dispatched first
     std::stable_sort(ids.begin(), ids.end(),
                      [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
-    // A group keeps one wavefront busy for as many columns as its longest target has.
-    // Groups far above the balanced share of a wavefront slot would stretch the kernel to
-    // their own length (one lane per target cannot split a target), so their targets go to
-    // the intra-sequence kernel, which spreads each pair over 64 lanes.
-    {
-        int64_t totalCols = 0;
-        for (size_t k = 0; k < ids.size(); k += kGroupTargets) totalCols += dbLen(db, ids[k]);
-        const int64_t slots = (int64_t)db->computeUnits * 12;
-        v->balancedCols = totalCols / std::max<int64_t>(slots, 1);
-        const int64_t limit = std::max<int64_t>(5 * v->balancedCols / 2, 512);
-        size_t cut = 0;
-        while (cut < ids.size() && dbLen(db, ids[cut]) > limit) cut += kGroupTargets;
-        cut = std::min(cut, ids.size());
-        if (cut > 0) {
-            v->longIds.insert(v->longIds.end(), ids.begin(), ids.begin() + (ptrdiff_t)cut);
-            ids.erase(ids.begin(), ids.begin() + (ptrdiff_t)cut);
-        }
-    }
     v->nPacked = (int)ids.size();
     v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
     std::vector<int64_t> groupOff(v->nGroups + 1, 0), chunkPrefix(v->nGroups + 1, 0), boundaryOff(v->nGroups + 1, 0);
@@ -316,6 +298,7 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
         boundaryOff[g + 1] = boundaryOff[g] + (int64_t)chunks * 4 * kLanes;
     }
     v->totalChunks = chunkPrefix[v->nGroups];
+    v->groupChunksHost.assign(groupChunks.begin(), groupChunks.begin() + v->nGroups);
     v->ids = ids;
     if (v->nGroups > 0) {
         int64_t* d_chunkPrefix = nullptr;
@@ -383,6 +366,7 @@ struct Search {
     int64_t start, end;
     int64_t n;
     int maxScore = 0, minScore = 0;
+    int64_t balancedChunks = 0;
 
     uint8_t* d_query = nullptr;
     int32_t* d_matrix = nullptr;
@@ -504,12 +488,32 @@ struct Search {
 
         std::shared_ptr<View> view;
         RC_TRY(getView(db, start, end, &view));
-        // not in the packed view: can be recomputed beside the packed kernel
+        // not handled by the packed kernel: can be recomputed beside it
         std::vector<PairJob> sideJobs;
         for (int32_t id : view->longIds) sideJobs.push_back(forwardJob(id, rules));
 
+        const int nStrips = std::max(1, (Q + kMaxStripRows - 1) / kMaxStripRows);
+        // strips of a group in flight (wavefronts per workgroup)
+        const int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
+        // A group keeps its wavefronts busy for (columns of its longest target) x (rounds of strips).
+        // Groups far above the balanced share of a workgroup slot would stretch the kernel to
+        // their own length (one lane per target cannot split a target), so the leading
+        // (longest) groups are skipped and their targets go to the intra-sequence kernel,
+        // which spreads each pair over 64 lanes.
+        int firstGroup = 0;
         if (view->nGroups > 0) {
-            const int nStrips = (Q + kMaxStripRows - 1) / kMaxStripRows;
+            int64_t total = 0;
+            for (int c : view->groupChunksHost) total += c;
+            const int64_t slots = (int64_t)db->computeUnits * std::max(1, 12 / waves);
+            const int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
+            while (firstGroup < view->nGroups && view->groupChunksHost[firstGroup] > limit) ++firstGroup;
+            const int skipped = std::min(firstGroup * kGroupTargets, view->nPacked);
+            for (int k = 0; k < skipped; ++k) sideJobs.push_back(forwardJob(view->ids[k], rules));
+            balancedChunks = total / std::max<int64_t>(slots, 1);
+        }
+        const int firstPos = std::min(firstGroup * kGroupTargets, view->nPacked);
+
+        if (view->nGroups > firstGroup) {
             const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
             const int qPad = nStrips * rows;
             const int nSym = A + 1;
@@ -520,20 +524,31 @@ struct Search {
             //   every true H, E, F >= -(3*open + (Q + L)*ext)   and   H <= min(Q, L)*maxScore
             const bool sw = mode == OPAL_MODE_SW;
             const bool halfFloat = sw && useHalf && maxScore <= 1024 && minScore >= -1024;
-            const InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
+            InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
+            int profileShift = 0;
             if (!sw) {
-                const int64_t lowSafe = (32000 - 3 * (int64_t)open - (int64_t)Q * ext) / std::max(ext, 1);
                 const int64_t pos = std::max(maxScore, 0);
-                const bool qFits = (int64_t)Q * pos < 32000;
-                // view order is longest first: the targets that do not fit form a prefix,
-                // empty targets (closed forms of the border) a suffix
-                int k = 0;
-                for (; k < view->nPacked; ++k) {
-                    const int64_t L = dbLen(db, view->ids[k]);
-                    if (L > 0 && L <= lowSafe && (qFits || L * pos < 32000)) break;
-                    jobs.push_back(forwardJob(view->ids[k], rules));
+                auto fitsPlain = [&](int64_t L) {
+                    return L > 0 && 3 * (int64_t)open + (Q + L) * ext < 32000 && std::min<int64_t>(Q, L) * pos < 32000;
+                };
+                // the shifted flavour stores X + (i + j) * ext: (Q + L) * ext more head-room
+                auto fitsDiag = [&](int64_t L) {
+                    return L > 0 && 3 * (int64_t)open + (Q + L + 2) * ext < 32000 &&
+                           std::min<int64_t>(Q, L) * pos + (Q + L) * ext < 32000;
+                };
+                // longest packed target that the plain flavour can take (view order: longest first)
+                int firstFit = firstPos;
+                while (firstFit < view->nPacked && !fitsPlain(dbLen(db, view->ids[firstFit]))) ++firstFit;
+                const bool diag = firstFit < view->nPacked && fitsDiag(dbLen(db, view->ids[firstFit])) &&
+                                  !getenv("MIOPAL_NO_DIAG_SHIFT");
+                if (diag) {
+                    flavour = kSignedInt16Diag;
+                    profileShift = 2 * ext;
                 }
-                for (int e = view->nPacked - 1; e >= k && dbLen(db, view->ids[e]) == 0; --e)
+                // the targets that do not fit form a prefix of the view, empty targets (closed
+                // forms of the border) a suffix; both are redone by the int32 kernel
+                for (int k = firstPos; k < firstFit; ++k) jobs.push_back(forwardJob(view->ids[k], rules));
+                for (int e = view->nPacked - 1; e >= firstFit && dbLen(db, view->ids[e]) == 0; --e)
                     jobs.push_back(forwardJob(view->ids[e], rules));
             }
             // query profile: profile[t][i] = S[q_i][t]; padding symbol and padding rows can
@@ -548,7 +563,7 @@ struct Search {
             const int16_t padValue = halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
-                for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t]);
+                for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t] + profileShift);
             // targets kept out of the packed view (too long for one lane each) are computed by the
             // int32 kernel on a side stream BESIDE the packed kernel; packed targets that need
             // the int32 kernel are redone after it, because both write the same result slots
@@ -578,7 +593,8 @@ struct Search {
             ia.pack = view->d_pack;
             ia.groupOff = view->d_groupOff;
             ia.groupChunks = view->d_groupChunks;
-            ia.nGroups = view->nGroups;
+            ia.nGroups = view->nGroups - firstGroup;
+            ia.groupBase = firstGroup;
             ia.profile = (const int16_t*)pp;
             ia.nSymbols = nSym;
             ia.qPad = qPad;
@@ -601,9 +617,7 @@ struct Search {
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.boundaryOff = view->d_boundaryOff;
-            ia.priorityChunks = (int)std::min<int64_t>(std::max<int64_t>(view->balancedCols / 4, 16), INT32_MAX);
-            // strips of a group in flight (wavefronts per workgroup)
-            const int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
+            ia.priorityChunks = (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
             if ((nStrips + waves - 1) / waves > 1) {
                 void *b0, *b1;
                 const size_t bytes = (size_t)view->totalChunks * 4 * kLanes * sizeof(uint2);
@@ -636,11 +650,12 @@ struct Search {
                 ws->timings.emplace_back(e0, e1);
                 db->lastTimed = ws;
             }
-            HIP_TRY(launchScatter(ia.score, (const uint8_t*)vo, view->d_ids, view->nPacked, start, d_score,
-                                  mayOverflow ? (int32_t*)ct : nullptr, stream));
+            const int nScatter = view->nPacked - firstPos;
+            HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos, nScatter,
+                                  start, d_score, mayOverflow ? (int32_t*)ct : nullptr, stream));
             if (locate)
-                HIP_TRY(launchScatterEnds(ia.endI, ia.endJ, view->d_ids, view->nPacked, start, d_endI, d_endJ,
-                                          stream));
+                HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos, nScatter,
+                                          start, d_endI, d_endJ, stream));
             if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws->evJoin, 0));
             if (mayOverflow) {
                 int32_t count = 0;
@@ -655,7 +670,7 @@ struct Search {
                     std::vector<uint8_t> flags((size_t)view->nPacked);
                     RC_TRY(download(flags.data(), (const uint8_t*)vo, flags.size(), stream));
                     HIP_TRY(hipStreamSynchronize(stream));
-                    for (int k = 0; k < view->nPacked; ++k)
+                    for (int k = firstPos; k < view->nPacked; ++k)
                         if (flags[k]) jobs.push_back(forwardJob(view->ids[k], rules));
                 }
             }

@@ -12,6 +12,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
             case kSwInt16: return launchInterseqSwInt16Loc(a, rowsPerStrip, waves, stream);
             case kSignedInt16: return launchInterseqSignedLoc(a, rowsPerStrip, waves, stream);
             case kSignedInt16AllCells: return launchInterseqSignedAllLoc(a, rowsPerStrip, waves, stream);
+            case kSignedInt16Diag: return launchInterseqSignedDiagLoc(a, rowsPerStrip, waves, stream);
         }
         return hipErrorInvalidValue;
     }
@@ -20,6 +21,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
         case kSwInt16: return launchInterseqSwInt16(a, rowsPerStrip, waves, stream);
         case kSignedInt16: return launchInterseqSigned(a, rowsPerStrip, waves, stream);
         case kSignedInt16AllCells: return launchInterseqSignedAll(a, rowsPerStrip, waves, stream);
+        case kSignedInt16Diag: return launchInterseqSignedDiag(a, rowsPerStrip, waves, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -83,6 +83,7 @@ static __device__ __forceinline__ uint32_t dup16(int v) { return ((uint32_t)v & 
 // ---- arithmetic flavours --------------------------------------------------------
 struct ArithSwI16 {
     static constexpr bool kFloor = true;    // Smith-Waterman
+    static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // a best at or above this may have clipped
     uint32_t open2, ext2;
     __device__ __forceinline__ ArithSwI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
@@ -104,6 +105,7 @@ struct ArithSwI16 {
 
 struct ArithSwF16 {
     static constexpr bool kFloor = true;
+    static constexpr bool kDiag = false;
     static constexpr int kLimit = 2048;
     uint32_t negOpen2, negExt2;
     static __device__ __forceinline__ uint32_t pack(int v) {
@@ -132,6 +134,7 @@ struct ArithSwF16 {
 
 struct ArithI16 {
     static constexpr bool kFloor = false;   // NW / HW / OV / anchored reverse pass
+    static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // ranges are checked statically by the host
     uint32_t open2, ext2;
     __device__ __forceinline__ ArithI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
@@ -148,6 +151,32 @@ struct ArithI16 {
     __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(pk_sub_sat_i16(x, ext2), hmo); }
     __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, -32768)); }
     static __device__ __forceinline__ uint32_t lowest() { return 0x80008000u; }  // acts as -infinity
+    static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
+};
+
+// Signed int16 on anti-diagonally shifted values: every cell holds X + (i + j) * ext.
+// Extending a gap then costs nothing (the shift of the next cell absorbs the ext), both
+// gap kinds open with the same h + (ext - open), and the diagonal step's 2 * ext is
+// folded into the query profile: 6 ops per cell pair instead of 8. Answers are shifted
+// back where they are read. Needs (Q + L) * ext of extra head-room (checked by the host).
+struct ArithI16Diag {
+    static constexpr bool kFloor = false;
+    static constexpr bool kDiag = true;
+    static constexpr int kLimit = 0x7fff;
+    uint32_t extMinusOpen2;
+    __device__ __forceinline__ ArithI16Diag(int open, int ext) : extMinusOpen2(dup16(max(ext - open, -32768))) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max_i16(pk_max_i16(d, e), f); }
+    __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
+        (void)held; (void)r;
+        best = pk_max_i16(best, h);
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_add_sat_i16(h, extMinusOpen2); }
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_add_sat_i16(h, extMinusOpen2); }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(x, hmo); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, -32768)); }
+    static __device__ __forceinline__ uint32_t lowest() { return 0x80008000u; }
     static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
 };
 
@@ -172,6 +201,7 @@ __global__ __launch_bounds__(W * kLanes)
 void interseq_kernel(InterseqArgs a) {
     static_assert(MULTI || W == 1, "a single strip needs a single wavefront");
     constexpr int kLowInt = Arith::kFloor ? 0 : INT32_MIN;
+    static_assert(!(Arith::kDiag && TRACK_ALL), "the shifted flavour has no all-cells maximum");
     constexpr bool kRegions = !Arith::kFloor;  // Smith-Waterman flavours only know the all-cells maximum
     constexpr int SLOTS = ProfileLayout<R>::kSlots;
     constexpr int NB = R / 8;
@@ -183,7 +213,7 @@ void interseq_kernel(InterseqArgs a) {
 
     const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x;  // one group of 128 targets per workgroup
+    const int g = blockIdx.x + a.groupBase;  // one group of 128 targets per workgroup
 
     uint4* prof = ldsProf[wave];
     const uint2* pack = a.pack + a.groupOff[g];
@@ -197,6 +227,17 @@ void interseq_kernel(InterseqArgs a) {
     const bool topGap = a.topGap, leftGap = a.leftGap;
     const int region = kRegions ? a.region : (int)kAllCells;
     const int open = a.gapOpen, ext = a.gapExt;
+    // value of a border cell k residues into a border (the other index is -1); the shifted
+    // flavour stores X + (i + j) * ext, which makes a penalised border constant
+    auto border = [&](bool gap, int k) -> int {
+        if (Arith::kDiag) return gap ? -(open + ext) : (k - 1) * ext;
+        return gap ? -(open + k * ext) : 0;
+    };
+    // shift a stored value of cell (i, j) back to its true value
+    auto unshift = [&](uint32_t v, int i, int j) -> uint32_t {
+        if (Arith::kDiag) return pk_sub_sat_i16(v, dup16((i + j) * ext));
+        return v;
+    };
 
     // per-lane target lengths (NW / OV take answers at each target's own last column)
     const size_t base = (size_t)g * kGroupTargets;
@@ -238,7 +279,6 @@ void interseq_kernel(InterseqArgs a) {
         }
 
         uint32_t hdiagTop = Arith::lowest();
-        uint32_t topH = 0;
         if (active) {
             // stage this strip's slice of the query profile into the wavefront's LDS region
             for (int idx = lane; idx < a.nSymbols * (R / 8); idx += kLanes) {
@@ -254,14 +294,13 @@ void interseq_kernel(InterseqArgs a) {
                 uint32_t hl;
                 if (Arith::kFloor) hl = 0u;
                 else if (i0 + r >= Q) hl = Arith::lowest();
-                else hl = ar.fromInt(leftGap ? -(open + (i0 + r) * ext) : 0);
+                else hl = ar.fromInt(border(leftGap, i0 + r));
                 H[r] = hl;
                 E[r] = ar.afterOpen(hl);
             }
             // H[i0-1][-1]: diagonal of the strip's first row in column 0
             if (Arith::kFloor) hdiagTop = 0u;
-            else hdiagTop = (s == 0 || !leftGap) ? ar.fromInt(0) : ar.fromInt(-(open + (i0 - 1) * ext));
-            topH = ar.fromInt(topGap ? -open : 0);  // H[-1][0]
+            else hdiagTop = s == 0 ? ar.fromInt(Arith::kDiag ? -2 * ext : 0) : ar.fromInt(border(leftGap, i0 - 1));
         }
 
         uint2 cur = {0, 0}, nxt = {0, 0};
@@ -310,9 +349,9 @@ void interseq_kernel(InterseqArgs a) {
                     uint32_t diag = hdiagTop;
                     uint32_t f;
                     if (!MULTI || s == 0) {
+                        const uint32_t topH = Arith::kFloor ? 0u : ar.fromInt(border(topGap, j));  // H[-1][j]
                         hdiagTop = topH;
                         f = ar.afterOpen(topH);
-                        if (topGap) topH = ar.afterExt(topH);
                     } else {
                         hdiagTop = b0.x;
                         f = b0.y;
@@ -397,6 +436,7 @@ void interseq_kernel(InterseqArgs a) {
 #pragma unroll
                                 for (int r = 1; r < R; ++r)
                                     if (r == rl) hq = H[r];
+                                hq = unshift(hq, Q - 1, j);
                                 const int qA = Arith::toInt(hq & 0xffffu), qB = Arith::toInt(hq >> 16);
                                 if (region == kLastCell) {
                                     if (j == lenA - 1) { runA = qA; colA = j; }
@@ -411,10 +451,18 @@ void interseq_kernel(InterseqArgs a) {
                             }
                             if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastMask != 0) != 0) {
                                 int mA = INT32_MIN, mB = INT32_MIN, ra = 0, rb = 0;
+                                uint32_t off = Arith::kDiag ? dup16((s * R + R - 1 + j) * ext) : 0u;
+                                const uint32_t step = Arith::kDiag ? dup16(ext) : 0u;
 #pragma unroll
                                 for (int r = R - 1; r >= 0; --r) {
+                                    const uint32_t offR = off;
+                                    if (Arith::kDiag) {
+                                        off -= step;  // running shift of the row above
+                                        asm volatile("" : "+v"(off));
+                                    }
                                     if (s * R + r < Q) {
-                                        const int hA = Arith::toInt(H[r] & 0xffffu), hB = Arith::toInt(H[r] >> 16);
+                                        const uint32_t hv = Arith::kDiag ? pk_sub_sat_i16(H[r], offR) : H[r];
+                                        const int hA = Arith::toInt(hv & 0xffffu), hB = Arith::toInt(hv >> 16);
                                         if (hA >= mA) { mA = hA; ra = r; }
                                         if (hB >= mB) { mB = hB; rb = r; }
                                     }
@@ -433,14 +481,27 @@ void interseq_kernel(InterseqArgs a) {
 #pragma unroll
                             for (int r = 1; r < R; ++r)
                                 if (r == rl) hq = H[r];
+                            hq = unshift(hq, Q - 1, j);
                             if (region == kLastCell) ans = selectHalves(ans, hq, lastMask);
                             else ans = ar.max2(ans, hq);  // last row; padded columns never exceed real ones
                         }
                         if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastMask != 0) != 0) {
                             // some lane is on its target's last column: maximum over this strip's rows
-                            uint32_t cm = H[0];
+                            // (the shift of row r is kept as a running packed value: one add per row
+                            // here instead of R live offsets)
+                            uint32_t off = Arith::kDiag ? dup16((s * R + j) * ext) : 0u;
+                            const uint32_t step = Arith::kDiag ? dup16(ext) : 0u;
+                            uint32_t cm = Arith::kDiag ? pk_sub_sat_i16(H[0], off) : H[0];
 #pragma unroll
-                            for (int r = 1; r < R; ++r) cm = ar.max2(cm, H[r]);
+                            for (int r = 1; r < R; ++r) {
+                                if (Arith::kDiag) {
+                                    off += step;  // halves stay below 32000: no carry between them
+                                    asm volatile("" : "+v"(off));
+                                    cm = ar.max2(cm, pk_sub_sat_i16(H[r], off));
+                                } else {
+                                    cm = ar.max2(cm, H[r]);
+                                }
+                            }
                             ans = selectHalves(ans, ar.max2(ans, cm), lastMask);
                         }
                     }
@@ -635,11 +696,13 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_kernel(Inte
             g = tier * gridDim.x + ((tier & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x);
             firstRound = false;
             if (g >= a.nGroups) continue;
+            g += a.groupBase;
         } else {
             g = 0;
             if (lane == 0) g = atomicAdd(a.workCounter, 1);
             g = __builtin_amdgcn_readfirstlane(g) + firstDynamic;
             if (g >= a.nGroups) break;
+            g += a.groupBase;
         }
         const uint2* pack = a.pack + a.groupOff[g];
         const int nChunks = a.groupChunks[g];

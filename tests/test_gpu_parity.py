@@ -108,6 +108,21 @@ def test_related_sequences_with_ties(capi, algo):
         compare(gpu, ref, "full", f"{algo} gaps {go}/{ge}")
 
 
+@pytest.mark.parametrize("switch", ["MIOPAL_NO_PAIR_TABLE", "MIOPAL_NO_DIAG_SHIFT"])
+def test_alternative_kernel_variants(capi, monkeypatch, switch):
+    # the variants the default dispatch does not pick on small inputs: v_perm profile
+    # fetch for one-strip SW, unshifted signed lanes for NW / HW / OV
+    monkeypatch.setenv(switch, "1")
+    rng = np.random.default_rng(17)
+    res, off = _data.random_db(rng, rng.integers(1, 500, size=700))
+    for qlen in (53, 150, 600):
+        q = _data.random_protein(rng, qlen)
+        for algo in ALGOS:
+            for mode in ("score", "end"):
+                gpu, ref = run_both(capi, q, res, off, B62, 3, 1, mode, algo)
+                compare(gpu, ref, mode, f"{switch} {algo}/{mode} Q={qlen}")
+
+
 @pytest.mark.parametrize("qlen", [1, 7, 8, 9, 53, 63, 64, 65, 100, 128, 129, 200, 333])
 def test_query_lengths_sw_score(capi, qlen):
     # strip boundaries of the inter-sequence kernel (8-row blocks, 64-row strips)
