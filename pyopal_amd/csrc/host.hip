@@ -640,10 +640,14 @@ struct Search {
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
                 ia.workCounter = (int*)wc;
-                HIP_TRY(launchInterseqPair(ia, rows, halfFloat, db->computeUnits, stream));
-            }
-            else
+                if (launchInterseqPair(ia, rows, halfFloat, db->computeUnits, stream) != hipSuccess) {
+                    // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant
+                    (void)hipGetLastError();
+                    HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
+                }
+            } else {
                 HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
+            }
             if (timed) {
                 HIP_TRY(hipEventRecord(e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
