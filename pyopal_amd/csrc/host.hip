@@ -75,7 +75,7 @@ struct PhaseTimer {
 };
 
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
-constexpr int64_t kDirBudget = 6ll << 30;  // bytes of direction workspace per traceback batch
+constexpr int64_t kDirBudget = 2ll << 30;  // bytes of direction workspace per traceback batch
 constexpr int64_t kInt32Safe = 1ll << 29;
 constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
 
