@@ -99,6 +99,42 @@ struct Workspace {
     hipStream_t aux = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
 
+    // Results go to the host through a pinned staging buffer: copying straight into the
+    // caller's pageable arrays makes the runtime pin and unpin those pages on every call
+    // (tens of milliseconds on fresh memory), a pinned bounce buffer does not.
+    void* pinned = nullptr;
+    size_t pinnedCap = 0, pinnedUsed = 0;
+    struct Pending { void* dst; size_t off, bytes; };
+    std::vector<Pending> pending;
+
+    int finishDownloads() {
+        if (pending.empty()) return 0;
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (const Pending& p : pending) memcpy(p.dst, (const char*)pinned + p.off, p.bytes);
+        pending.clear();
+        pinnedUsed = 0;
+        return 0;
+    }
+    int stageDownload(void* dst, const void* deviceSrc, size_t bytes) {
+        if (bytes == 0) return 0;
+        const size_t aligned = (bytes + 255) & ~(size_t)255;
+        if (pinnedUsed + aligned > pinnedCap) {
+            RC_TRY(finishDownloads());
+            if (aligned > pinnedCap) {
+                if (pinned) HIP_TRY(hipHostFree(pinned));
+                pinned = nullptr;
+                pinnedCap = 0;
+                const size_t want = aligned + aligned / 4 + (1u << 20);
+                HIP_TRY(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+                pinnedCap = want;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync((char*)pinned + pinnedUsed, deviceSrc, bytes, hipMemcpyDeviceToHost, stream));
+        pending.push_back({dst, pinnedUsed, bytes});
+        pinnedUsed += aligned;
+        return 0;
+    }
+
     int ensureAux() {
         if (aux) return 0;
         HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -135,6 +171,7 @@ struct Workspace {
         }
         for (void* p : buf)
             if (p) (void)hipFree(p);
+        if (pinned) (void)hipHostFree(pinned);
         if (evFork) (void)hipEventDestroy(evFork);
         if (evJoin) (void)hipEventDestroy(evJoin);
         if (aux) (void)hipStreamDestroy(aux);
@@ -486,8 +523,10 @@ struct Search {
             return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
         }
 
+        PhaseTimer spt;
         std::shared_ptr<View> view;
         RC_TRY(getView(db, start, end, &view));
+        spt.mark("    view lookup");
         // not handled by the packed kernel: can be recomputed beside it
         std::vector<PairJob> sideJobs;
         for (int32_t id : view->longIds) sideJobs.push_back(forwardJob(id, rules));
@@ -568,7 +607,7 @@ struct Search {
             // int32 kernel on a side stream BESIDE the packed kernel; packed targets that need
             // the int32 kernel are redone after it, because both write the same result slots
             bool forked = false;
-            if (!sideJobs.empty()) {
+            if (!sideJobs.empty() && !getenv("MIOPAL_NO_SIDE_STREAM")) {
                 RC_TRY(ws->ensureAux());
                 RC_TRY(ensurePairInputs());
                 HIP_TRY(hipEventRecord(ws->evFork, stream));
@@ -577,6 +616,7 @@ struct Search {
                 HIP_TRY(hipEventRecord(ws->evJoin, ws->aux));
                 sideJobs.clear();
                 forked = true;
+                spt.mark("    side jobs enqueued");
             }
             void *pp, *vs, *vo, *ct;
             RC_TRY(ws->get(kProfile, prof.size() * sizeof(int16_t), &pp));
@@ -617,7 +657,7 @@ struct Search {
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.boundaryOff = view->d_boundaryOff;
-            ia.priorityChunks = (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
+            ia.priorityChunks = getenv("MIOPAL_NO_PRIORITY") ? INT32_MAX : (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
             if ((nStrips + waves - 1) / waves > 1) {
                 void *b0, *b1;
                 const size_t bytes = (size_t)view->totalChunks * 4 * kLanes * sizeof(uint2);
@@ -661,6 +701,11 @@ struct Search {
                 HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos, nScatter,
                                           start, d_endI, d_endJ, stream));
             if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws->evJoin, 0));
+            spt.mark("    packed kernel enqueued");
+            if (spt.on) {
+                HIP_TRY(hipStreamSynchronize(stream));
+                spt.mark("    packed + side kernels done");
+            }
             if (mayOverflow) {
                 int32_t count = 0;
                 RC_TRY(download(&count, (const int32_t*)ct, 1, stream));
@@ -870,11 +915,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         RC_TRY(ws->get(kEndJ, (size_t)n * sizeof(int32_t), &pj));
     }
     RC_TRY(s.scorePass((int32_t*)ps, (int32_t*)pi, (int32_t*)pj));
-    RC_TRY(download(score, (const int*)ps, (size_t)n, stream));
+    RC_TRY(ws->stageDownload(score, ps, (size_t)n * sizeof(int)));
     if (wantEnd) {
-        RC_TRY(download(endQuery, (const int*)pi, (size_t)n, stream));
-        RC_TRY(download(endTarget, (const int*)pj, (size_t)n, stream));
+        RC_TRY(ws->stageDownload(endQuery, pi, (size_t)n * sizeof(int)));
+        RC_TRY(ws->stageDownload(endTarget, pj, (size_t)n * sizeof(int)));
     }
+    RC_TRY(ws->finishDownloads());
     HIP_TRY(hipStreamSynchronize(stream));
     pt.mark("score/end pass + D2H");
     if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
@@ -919,10 +965,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         RC_TRY(ws->get(kRJ, live.size() * sizeof(int32_t), &rj));
         RC_TRY(s.runPairs(jobs, false, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj, nullptr));
         std::vector<int32_t> hs(live.size()), hi(live.size()), hj(live.size());
-        RC_TRY(download(hs.data(), (const int32_t*)rs, hs.size(), stream));
-        RC_TRY(download(hi.data(), (const int32_t*)ri, hi.size(), stream));
-        RC_TRY(download(hj.data(), (const int32_t*)rj, hj.size(), stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        RC_TRY(ws->stageDownload(hs.data(), rs, hs.size() * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(hi.data(), ri, hi.size() * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(hj.data(), rj, hj.size() * sizeof(int32_t)));
+        RC_TRY(ws->finishDownloads());
         for (size_t x = 0; x < live.size(); ++x) {
             const int64_t k = live[x];
             if (hs[x] != score[k] || hi[x] < 0 || hj[x] < 0)
@@ -984,10 +1030,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         if (pt.on) { HIP_TRY(hipStreamSynchronize(stream)); pt.mark("  trace + walk kernels"); }
         std::vector<uint8_t> ops((size_t)opsOff.back());
         std::vector<int32_t> lens(jobs.size()), tscore(jobs.size());
-        RC_TRY(download(ops.data(), (const uint8_t*)po, ops.size(), stream));
-        RC_TRY(download(lens.data(), (const int32_t*)plen, lens.size(), stream));
-        RC_TRY(download(tscore.data(), (const int32_t*)pscore, tscore.size(), stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        RC_TRY(ws->stageDownload(ops.data(), po, ops.size()));
+        RC_TRY(ws->stageDownload(lens.data(), plen, lens.size() * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(tscore.data(), pscore, tscore.size() * sizeof(int32_t)));
+        RC_TRY(ws->finishDownloads());
         pt.mark("  ops D2H");
         for (size_t x = 0; x < jobs.size(); ++x) {
             const int64_t k = live[first + x];
