@@ -73,6 +73,7 @@ struct IntraseqArgs {
     int32_t* score;
     int32_t* endI;            // query coordinate of the best cell (pass coordinates)
     int32_t* endJ;            // target coordinate
+    int raisePriority;        // run the wavefronts at s_setprio 3 (side-stream launches)
 };
 
 struct WalkArgs {

@@ -488,6 +488,7 @@ struct Search {
         a.score = d_score;
         a.endI = d_endI;
         a.endJ = d_endJ;
+        a.raisePriority = (on != stream && !getenv("MIOPAL_NO_PRIORITY")) ? 1 : 0;
         HIP_TRY(launchIntraseq(a, trace, on));
         return 0;
     }

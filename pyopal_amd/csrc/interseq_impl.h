@@ -96,7 +96,6 @@ struct ArithSwI16 {
     __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }
     __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_sub_sat_u16(h, open2); }
     __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_sub_sat_u16(h, open2); }
-    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_sub_sat_u16(h, ext2); }
     __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(pk_sub_sat_u16(x, ext2), hmo); }
     __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, 0)); }
     static __device__ __forceinline__ uint32_t lowest() { return 0u; }
@@ -123,7 +122,6 @@ struct ArithSwF16 {
     __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_max3_f16(pk_add_f16(h, negOpen2), 0u, 0u); }
     // inside a cell the floor comes with the max3 of gap(), so the open step needs none
     __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_add_f16(h, negOpen2); }
-    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_max3_f16(pk_add_f16(h, negExt2), 0u, 0u); }
     __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max3_f16(pk_add_f16(x, negExt2), hmo, 0u); }
     __device__ __forceinline__ uint32_t fromInt(int v) const { return pack(max(v, 0)); }
     static __device__ __forceinline__ uint32_t lowest() { return 0u; }
@@ -147,7 +145,6 @@ struct ArithI16 {
     __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }
     __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return pk_sub_sat_i16(h, open2); }
     __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return pk_sub_sat_i16(h, open2); }
-    __device__ __forceinline__ uint32_t afterExt(uint32_t h) const { return pk_sub_sat_i16(h, ext2); }
     __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max_i16(pk_sub_sat_i16(x, ext2), hmo); }
     __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, -32768)); }
     static __device__ __forceinline__ uint32_t lowest() { return 0x80008000u; }  // acts as -infinity

@@ -40,6 +40,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
 
     const PairJob job = a.jobs[jobIdx];
     const int Q = job.qLen, L = job.tLen;
+    // a pair is a chain of L + 63 dependent steps: beside the packed kernel (side stream)
+    // it should win the SIMD's issue arbitration, it needs few slots
+    if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
     const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
     const int region = (job.rules >> 4) & 3;
     const int open = a.gapOpen, ext = a.gapExt;
@@ -60,8 +63,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             int hLeft = leftGap ? -(open + i * ext) : 0;  // H[i][-1]
             int eLeft = kNegInf;
             int hDiag = (i == 0) ? 0 : (leftGap ? -(open + (i - 1) * ext) : 0);  // H[i-1][-1]
-            int hCur = 0, fCur = kNegInf, tres = 0;
-            int tbuf = 0, bH = 0, bF = kNegInf;
+            int hCur = 0, fCur = kNegInf;
             const int2* bin = a.boundary[(s + 1) & 1] + job.wsOff;
             int2* bout = a.boundary[s & 1] + job.wsOff;
             const bool lastStrip = s + 1 == nStrips;
@@ -73,62 +75,80 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             const bool candOnLastCol = region == kLastRowCol || (region == kLastCell && rowIsLast);
             const bool writer = lane == kLanes - 1 && !lastStrip;
 
-            for (int k = 0; k < nSteps; ++k) {
-                if ((k & 63) == 0) {
-                    const int kk = k + lane;
-                    tbuf = kk < L ? tptr[(int64_t)kk * job.tStep] : 0;
+            // A step is a chain of dependent operations (a pair is L + 63 steps long, however
+            // many wavefronts the chip has), so everything that does not depend on the DP values
+            // is taken off that chain:
+            //  * target residues travel down the lanes in a shift register that runs ONE step
+            //    ahead of the DP, so the substitution score of step k + 1 is fetched from LDS
+            //    while step k is computed;
+            //  * the values entering lane 0 (next residue, row above the strip) sit in 64-entry
+            //    lane buffers that are rotated by one lane per step (wave_rol:1); wave_shr:1
+            //    keeps its `old` operand in lane 0, so feeding lane 0 costs no select.
+            constexpr int kShr1 = 0x138, kRol1 = 0x134;
+            int tres = lane == 0 ? (int)tptr[0] : 0;  // residue of step 0 (lane 0 only)
+            int scCur = srow[tres];
+            int tbuf = 0, bH = 0, bF = kNegInf;
+
+            for (int k0 = 0; k0 < nSteps; k0 += kLanes) {
+                {
+                    const int kt = k0 + 1 + lane;  // residues of steps k0+1 .. k0+64
+                    tbuf = kt < L ? tptr[(int64_t)kt * job.tStep] : 0;
                     if (s > 0) {
-                        int2 b = kk < L ? bin[kk] : make_int2(0, kNegInf);
+                        const int kb = k0 + lane;  // row above the strip, columns k0 .. k0+63
+                        const int2 b = kb < L ? bin[kb] : make_int2(0, kNegInf);
                         bH = b.x;
                         bF = b.y;
                     }
                 }
-                // lane 0 takes the row above the strip (border or previous strip), every other
-                // lane what its upper neighbour produced one step earlier: wave_shr:1 keeps
-                // `old` in lane 0, so the select is free
-                const int sel = k & 63;
-                const int t0 = __builtin_amdgcn_readlane(tbuf, sel);
-                int h0, f0;
-                if (s == 0) {
-                    h0 = topGap ? -(open + k * ext) : 0;
-                    f0 = kNegInf;
-                } else {
-                    h0 = __builtin_amdgcn_readlane(bH, sel);
-                    f0 = __builtin_amdgcn_readlane(bF, sel);
+                const int kEnd = min(k0 + kLanes, nSteps);
+                for (int k = k0; k < kEnd; ++k) {
+                    // residue stage of step k + 1
+                    const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
+                    tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
+                    const int scNext = srow[tnext];
+                    tres = tnext;
+
+                    // DP stage of step k
+                    int hTop = bH, fTop = bF;
+                    if (s == 0) {
+                        hTop = topGap ? -(open + k * ext) : 0;
+                        fTop = kNegInf;
+                    } else {
+                        bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
+                        bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
+                    }
+                    const int hUp = __builtin_amdgcn_update_dpp(hTop, hCur, kShr1, 0xf, 0xf, false);
+                    const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
+                    const int j = k - lane;
+                    const bool valid = rowActive && (unsigned)j < (unsigned)L;
+                    const int eOpen = hLeft - open, eExt = eLeft - ext;
+                    const int fOpen = hUp - open, fExt = fUp - ext;
+                    const int e = max(eOpen, eExt);
+                    const int f = max(fOpen, fExt);
+                    const int d = hDiag + scCur;
+                    int h = max(d, max(e, f));
+                    if (floor0) h = max(h, 0);
+                    if (TRACE) {
+                        // priority diag > E (target gap) > F (query gap); inside a gap,
+                        // closing it (back to H) is preferred to extending it
+                        uint8_t code = (h == d) ? 0 : (h == e) ? 1 : 2;
+                        if (e == eOpen) code |= 4;
+                        if (f == fOpen) code |= 8;
+                        dirs[(size_t)k * kLanes + lane] = code;
+                    }
+                    hDiag = valid ? hUp : hDiag;
+                    hLeft = valid ? h : hLeft;
+                    eLeft = valid ? e : eLeft;
+                    hCur = valid ? h : hCur;
+                    fCur = valid ? f : fCur;
+                    const bool cand = candAlways || (candOnLastCol && j == L - 1);
+                    const bool take = valid && cand && (h > best || (h == best && j < bj));
+                    best = take ? h : best;
+                    bi = take ? i : bi;
+                    bj = take ? j : bj;
+                    if (writer && valid) bout[j] = make_int2(h, f);
+                    scCur = scNext;
                 }
-                const int hUp = __builtin_amdgcn_update_dpp(h0, hCur, 0x138, 0xf, 0xf, false);
-                const int fUp = __builtin_amdgcn_update_dpp(f0, fCur, 0x138, 0xf, 0xf, false);
-                const int tin = __builtin_amdgcn_update_dpp(t0, tres, 0x138, 0xf, 0xf, false);
-                const int j = k - lane;
-                const bool valid = rowActive && j >= 0 && j < L;
-                const int sc = srow[tin];
-                const int eOpen = hLeft - open, eExt = eLeft - ext;
-                const int fOpen = hUp - open, fExt = fUp - ext;
-                const int e = max(eOpen, eExt);
-                const int f = max(fOpen, fExt);
-                const int d = hDiag + sc;
-                int h = max(d, max(e, f));
-                if (floor0) h = max(h, 0);
-                if (TRACE) {
-                    // priority diag > E (target gap) > F (query gap); inside a gap,
-                    // closing it (back to H) is preferred to extending it
-                    uint8_t code = (h == d) ? 0 : (h == e) ? 1 : 2;
-                    if (e == eOpen) code |= 4;
-                    if (f == fOpen) code |= 8;
-                    dirs[(size_t)k * kLanes + lane] = code;
-                }
-                hDiag = valid ? hUp : hDiag;
-                hLeft = valid ? h : hLeft;
-                eLeft = valid ? e : eLeft;
-                hCur = valid ? h : hCur;
-                fCur = valid ? f : fCur;
-                tres = valid ? tin : tres;
-                const bool cand = candAlways || (candOnLastCol && j == L - 1);
-                const bool take = valid && cand && (h > best || (h == best && j < bj));
-                best = take ? h : best;
-                bi = take ? i : bi;
-                bj = take ? j : bj;
-                if (writer && valid) bout[j] = make_int2(h, f);
             }
             if (!lastStrip) __threadfence();
         }
