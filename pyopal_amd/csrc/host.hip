@@ -493,6 +493,27 @@ struct Search {
         return 0;
     }
 
+    // Same with a job list that already sits in HBM and needs no strip-boundary workspace
+    // (every query piece fits one 64-row strip).
+    int runDeviceJobs(const PairJob* d_jobs, int nJobs, int32_t* d_score, int32_t* d_endI, int32_t* d_endJ) {
+        if (nJobs <= 0) return 0;
+        RC_TRY(ensurePairInputs());
+        IntraseqArgs a{};
+        a.jobs = d_jobs;
+        a.nJobs = nJobs;
+        a.residues = db->d_residues;
+        a.query = d_query;
+        a.matrix = d_matrix;
+        a.alphabet = A;
+        a.gapOpen = open;
+        a.gapExt = ext;
+        a.score = d_score;
+        a.endI = d_endI;
+        a.endJ = d_endJ;
+        HIP_TRY(launchIntraseq(a, false, stream));
+        return 0;
+    }
+
     PairJob forwardJob(int64_t id, int rules) const {
         PairJob j{};
         j.tOff = db->offsets[id];
@@ -938,7 +959,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             alignmentLength[k] = 0;
         }
     }
-    if (flat) flatOff[0] = 0;
+    if (flat) {
+        flatOff[0] = 0;
+        flatOps->reserve((size_t)n * (size_t)std::min<int64_t>(queryLength + 16, 4096));
+    }
     std::vector<int64_t> live;  // slots with a non-empty alignment
     for (int64_t k = 0; k < n; ++k)
         if (endQuery[k] >= 0 && endTarget[k] >= 0) live.push_back(k);
@@ -946,37 +970,49 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         for (int64_t k : live) startQuery[k] = startTarget[k] = 0;
     } else if (!live.empty()) {
         const DpRules rr{1, 1, 0, fr.region};
-        std::vector<PairJob> jobs(live.size());
-        for (size_t x = 0; x < live.size(); ++x) {
-            const int64_t k = live[x];
-            PairJob& j = jobs[x];
-            j = PairJob{};
-            j.tOff = db->offsets[(size_t)(start + k)] + endTarget[k];
-            j.tLen = endTarget[k] + 1;
-            j.tStep = -1;
-            j.qOff = endQuery[k];
-            j.qLen = endQuery[k] + 1;
-            j.qStep = -1;
-            j.rules = packRules(rr);
-            j.out = (int32_t)x;
-        }
         void *rs, *ri, *rj;
-        RC_TRY(ws->get(kRScore, live.size() * sizeof(int32_t), &rs));
-        RC_TRY(ws->get(kRI, live.size() * sizeof(int32_t), &ri));
-        RC_TRY(ws->get(kRJ, live.size() * sizeof(int32_t), &rj));
-        RC_TRY(s.runPairs(jobs, false, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj, nullptr));
-        std::vector<int32_t> hs(live.size()), hi(live.size()), hj(live.size());
-        RC_TRY(ws->stageDownload(hs.data(), rs, hs.size() * sizeof(int32_t)));
-        RC_TRY(ws->stageDownload(hi.data(), ri, hi.size() * sizeof(int32_t)));
-        RC_TRY(ws->stageDownload(hj.data(), rj, hj.size() * sizeof(int32_t)));
+        const bool onDevice = queryLength <= kLanes;  // no strip workspace: jobs are built in HBM
+        const size_t nOut = onDevice ? (size_t)n : live.size();
+        RC_TRY(ws->get(kRScore, nOut * sizeof(int32_t), &rs));
+        RC_TRY(ws->get(kRI, nOut * sizeof(int32_t), &ri));
+        RC_TRY(ws->get(kRJ, nOut * sizeof(int32_t), &rj));
+        if (onDevice) {
+            void* pjobs;
+            RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
+            // pi / pj still hold the end locations of the forward pass (slice order)
+            HIP_TRY(launchReverseJobs((int)n, (const int32_t*)pi, (const int32_t*)pj, db->d_offsets + start,
+                                      packRules(rr), (PairJob*)pjobs, stream));
+            RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
+        } else {
+            std::vector<PairJob> jobs(live.size());
+            for (size_t x = 0; x < live.size(); ++x) {
+                const int64_t k = live[x];
+                PairJob& j = jobs[x];
+                j = PairJob{};
+                j.tOff = db->offsets[(size_t)(start + k)] + endTarget[k];
+                j.tLen = endTarget[k] + 1;
+                j.tStep = -1;
+                j.qOff = endQuery[k];
+                j.qLen = endQuery[k] + 1;
+                j.qStep = -1;
+                j.rules = packRules(rr);
+                j.out = (int32_t)x;
+            }
+            RC_TRY(s.runPairs(jobs, false, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj, nullptr));
+        }
+        std::unique_ptr<int32_t[]> hs(new int32_t[nOut]), hi(new int32_t[nOut]), hj(new int32_t[nOut]);
+        RC_TRY(ws->stageDownload(hs.get(), rs, nOut * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(hi.get(), ri, nOut * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(hj.get(), rj, nOut * sizeof(int32_t)));
         RC_TRY(ws->finishDownloads());
         for (size_t x = 0; x < live.size(); ++x) {
             const int64_t k = live[x];
-            if (hs[x] != score[k] || hi[x] < 0 || hj[x] < 0)
+            const size_t o = onDevice ? (size_t)k : x;
+            if (hs[o] != score[k] || hi[o] < 0 || hj[o] < 0)
                 return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
                             (long long)(start + k));
-            startQuery[k] = endQuery[k] - hi[x];
-            startTarget[k] = endTarget[k] - hj[x];
+            startQuery[k] = endQuery[k] - hi[o];
+            startTarget[k] = endTarget[k] - hj[o];
         }
     }
 
@@ -1029,11 +1065,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         wa.opsLen = (int32_t*)plen;
         HIP_TRY(launchWalk(wa, stream));
         if (pt.on) { HIP_TRY(hipStreamSynchronize(stream)); pt.mark("  trace + walk kernels"); }
-        std::vector<uint8_t> ops((size_t)opsOff.back());
-        std::vector<int32_t> lens(jobs.size()), tscore(jobs.size());
-        RC_TRY(ws->stageDownload(ops.data(), po, ops.size()));
-        RC_TRY(ws->stageDownload(lens.data(), plen, lens.size() * sizeof(int32_t)));
-        RC_TRY(ws->stageDownload(tscore.data(), pscore, tscore.size() * sizeof(int32_t)));
+        const size_t opsBytes = (size_t)opsOff.back();
+        std::unique_ptr<uint8_t[]> ops(new uint8_t[std::max<size_t>(opsBytes, 1)]);
+        std::unique_ptr<int32_t[]> lens(new int32_t[jobs.size()]), tscore(new int32_t[jobs.size()]);
+        RC_TRY(ws->stageDownload(ops.get(), po, opsBytes));
+        RC_TRY(ws->stageDownload(lens.get(), plen, jobs.size() * sizeof(int32_t)));
+        RC_TRY(ws->stageDownload(tscore.get(), pscore, jobs.size() * sizeof(int32_t)));
         RC_TRY(ws->finishDownloads());
         pt.mark("  ops D2H");
         for (size_t x = 0; x < jobs.size(); ++x) {
@@ -1042,7 +1079,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
                             tscore[x], score[k], (long long)(start + k));
             const int len = lens[x];
-            const uint8_t* src = ops.data() + opsOff[x + 1] - len;
+            const uint8_t* src = ops.get() + opsOff[x + 1] - len;
             if (flat) {
                 // jobs are visited in increasing target order, so appending keeps slice order
                 flatOps->insert(flatOps->end(), src, src + len);

@@ -221,6 +221,36 @@ __global__ void walk_kernel(WalkArgs a) {
     a.opsLen[idx] = len;
 }
 
+// Jobs of the start-location pass, built where the end locations already are (HBM):
+// reversed prefixes q[0..endQ], t[0..endT] anchored on the end cell. Targets without an
+// end cell get an empty job (its outputs are ignored by the host).
+__global__ void reverse_jobs_kernel(int n, const int32_t* endQ, const int32_t* endT,
+                                    const int64_t* offsets, int rules, PairJob* jobs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int qe = endQ[k], te = endT[k];
+    PairJob j{};
+    j.out = k;
+    j.rules = rules;
+    j.tStep = -1;
+    j.qStep = -1;
+    if (qe >= 0 && te >= 0) {
+        j.tOff = offsets[k] + te;
+        j.tLen = te + 1;
+        j.qOff = qe;
+        j.qLen = qe + 1;
+    }
+    jobs[k] = j;
+}
+
+hipError_t launchReverseJobs(int n, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
+                             int rules, PairJob* jobs, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reverse_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, endQ, endT, offsets,
+                       rules, jobs);
+    return hipGetLastError();
+}
+
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
     const int blocks = (a.nJobs + kJobsPerBlock - 1) / kJobsPerBlock;
