@@ -162,7 +162,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": pmc_traffic() if (N, L) == (1_000_000, 300) else None,
-                "traffic_source": "profiles/r01b_pmc_interseq_pair_kernel.json (separate rocprofv3 --pmc passes "
+                "traffic_source": "profiles/r01d_pmc_interseq_pair_kernel.json (separate rocprofv3 --pmc passes "
                                   "FETCH_SIZE x2 + WRITE_SIZE, same kernel and workload)",
                 "kernel": "interseq_pair_kernel<56, ArithSwF16>",
                 "kernel_ms": round(k_ms, 4),
@@ -219,7 +219,7 @@ def extras(db, query, matrix, Q, N, L):
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed PMC summary
     (counters cannot be collected from inside the timed run)."""
-    path = os.path.join(ROOT, "profiles", "r01b_pmc_interseq_pair_kernel.json")
+    path = os.path.join(ROOT, "profiles", "r01d_pmc_interseq_pair_kernel.json")
     try:
         with open(path) as f:
             return float(json.load(f)["hbm_traffic_bytes_per_launch"])
