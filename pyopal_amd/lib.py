@@ -91,7 +91,7 @@ class Alphabet:
     """
 
     _DEFAULT_LETTERS = "ARNDCQEGHILKMFPSTWYVBZX*"
-    __slots__ = ("letters", "length", "_unknown", "_table", "_letters")
+    __slots__ = ("letters", "length", "_unknown", "_table", "_trans", "_letters")
 
     def __init__(self, letters: str = _DEFAULT_LETTERS):
         if not isinstance(letters, str):
@@ -106,15 +106,16 @@ class Alphabet:
         self.length = len(letters)
         self._unknown = letters.find("*")
         self._letters = np.frombuffer(letters.encode("ascii"), dtype=np.uint8).copy()
-        # -2: not a letter; -1: letter without a code (alphabet has no wildcard)
-        table = np.full(256, -2, dtype=np.int16)
+        # 255: not a letter; 254: letter without a code (alphabet has no wildcard)
+        table = np.full(256, 255, dtype=np.uint8)
         for c in range(256):
             if (65 <= c <= 90) or (97 <= c <= 122):
-                table[c] = self._unknown
+                table[c] = self._unknown if self._unknown >= 0 else 254
         for i, x in enumerate(self._letters):
             if (65 <= x <= 90) or (97 <= x <= 122):
                 table[x] = i
         self._table = table
+        self._trans = table.tobytes()  # 256-entry table for bytes.translate
 
     def __len__(self):
         return self.length
@@ -152,25 +153,31 @@ class Alphabet:
         return hash(self.letters)
 
     # -- bulk forms used by Database --------------------------------------------
-    def _encode_array(self, sequence) -> np.ndarray:
+    def _encode_bytes(self, sequence) -> bytes:
+        """Ordinal encoding of a str / bytes-like sequence in one C-level pass."""
         if isinstance(sequence, str):
-            sequence = sequence.encode("ascii")
-        raw = np.frombuffer(memoryview(sequence).cast("B"), dtype=np.uint8)
-        codes = self._table[raw]
-        if codes.size and codes.min() < 0:
-            pos = int(np.argmax(codes < 0))
-            letter = int(raw[pos])
-            if codes[pos] == -2:
+            sequence = sequence.encode("ascii", "replace")
+        elif not isinstance(sequence, (bytes, bytearray)):
+            sequence = memoryview(sequence).cast("B").tobytes()
+        codes = sequence.translate(self._trans)
+        if b"\xff" in codes or b"\xfe" in codes:
+            bad = [p for p in (codes.find(b"\xff"), codes.find(b"\xfe")) if p >= 0]
+            pos = min(bad)
+            letter = sequence[pos]
+            if codes[pos] == 255:
                 raise ValueError(f"character outside ASCII range: {letter!r}")
             raise ValueError(f"non-alphabet character in sequence: {chr(letter)!r}")
-        return codes.astype(np.uint8)
+        return bytes(codes)
+
+    def _encode_array(self, sequence) -> np.ndarray:
+        return np.frombuffer(self._encode_bytes(sequence), dtype=np.uint8)
 
     def encode_into(self, sequence, encoded) -> None:
         src = memoryview(sequence).cast("B")
         dst = memoryview(encoded).cast("B")
         if len(src) != len(dst):
             raise ValueError("Buffers do not have the same dimensions")
-        dst[:] = self._encode_array(src).tobytes()
+        dst[:] = self._encode_bytes(src)
 
     def decode_into(self, encoded, sequence) -> None:
         src = np.frombuffer(memoryview(encoded).cast("B"), dtype=np.uint8)
@@ -183,7 +190,7 @@ class Alphabet:
         dst[:] = self._letters[src].tobytes()
 
     def encode(self, sequence) -> bytes:
-        return self._encode_array(sequence).tobytes()
+        return self._encode_bytes(sequence)
 
     def decode(self, encoded) -> str:
         decoded = bytearray(len(encoded))
@@ -356,6 +363,33 @@ class Database(BaseDatabase):
             self._invalidate()
 
     def extend(self, sequences) -> None:
+        # Bulk path (the reference encodes sequence by sequence, lib.pyx:586-636; here one
+        # table look-up over the concatenation replaces a Python-level loop per residue):
+        # lists of str / bytes are joined, encoded once and cut back at their lengths.
+        if isinstance(sequences, (list, tuple)) and len(sequences) > 8:
+            if all(type(x) is str for x in sequences):
+                joined = "".join(sequences).encode("ascii", "replace")
+            elif all(type(x) is bytes for x in sequences):
+                joined = b"".join(sequences)
+            else:
+                joined = None
+            if joined is not None:
+                lengths = [len(x) for x in sequences]
+                try:
+                    encoded = self.alphabet.encode(joined)
+                except ValueError:
+                    encoded = None  # let the per-sequence path raise for the offending one
+                if encoded is not None and len(encoded) == sum(lengths):
+                    pieces = []
+                    offset = 0
+                    for n in lengths:
+                        pieces.append(encoded[offset:offset + n])
+                        offset += n
+                    with self.lock.write:
+                        self._sequences.extend(pieces)
+                        self._lengths.extend(lengths)
+                        self._invalidate()
+                    return
         for sequence in sequences:
             self.append(sequence)
 
@@ -425,190 +459,13 @@ class Database(BaseDatabase):
 
 # --- Results ----------------------------------------------------------------------
 
-class ScoreResult:
-    """Result of a search in ``score`` mode (``src/pyopal/lib.pyx:783-834``)."""
-
-    __slots__ = ("_target_index", "_score", "_score_set", "_query_end", "_target_end",
-                 "_query_start", "_target_start", "_ops", "_query_length", "_target_length")
-
-    def __new__(cls, *args, **kwargs):
-        self = object.__new__(cls)
-        self._target_index = -1
-        self._score = 0
-        self._score_set = False
-        self._query_end = self._target_end = -1
-        self._query_start = self._target_start = -1
-        self._ops = None
-        self._query_length = self._target_length = -1
-        return self
-
-    def __init__(self, target_index: int, score: int):
-        if target_index < 0:
-            raise OverflowError("can't convert negative value to size_t")
-        self._target_index = target_index
-        self._score = score
-        self._score_set = True
-
-    def __repr__(self):
-        return f"{type(self).__name__}({self.target_index}, score={self.score!r})"
-
-    def __reduce__(self):
-        return type(self), (self.target_index, self.score)
-
-    def __eq__(self, other):
-        if not isinstance(other, ScoreResult):
-            return NotImplemented
-        return self.__reduce__()[1] == other.__reduce__()[1]
-
-    __hash__ = None
-
-    @property
-    def target_index(self) -> int:
-        assert self._target_index >= 0
-        return self._target_index
-
-    @property
-    def score(self) -> int:
-        assert self._score_set
-        return self._score
-
-
-class EndResult(ScoreResult):
-    """Result of a search in ``end`` mode (``src/pyopal/lib.pyx:837-881``)."""
-
-    __slots__ = ()
-
-    def __init__(self, target_index: int, score: int, query_end: int, target_end: int):
-        super().__init__(target_index, score)
-        self._query_end = query_end
-        self._target_end = target_end
-
-    def __repr__(self):
-        return (f"{type(self).__name__}({self.target_index}, score={self.score!r}, "
-                f"query_end={self.query_end!r}, target_end={self.target_end!r})")
-
-    def __reduce__(self):
-        return type(self), (self.target_index, self.score, self.query_end, self.target_end)
-
-    @property
-    def query_end(self) -> int:
-        assert self._query_end >= 0
-        return self._query_end
-
-    @property
-    def target_end(self) -> int:
-        assert self._target_end >= 0
-        return self._target_end
-
-
-_OPS_TO_TEXT = bytes.maketrans(bytes([0, 1, 2, 3]), b"MDIX")  # src/pyopal/lib.pyx:991
-
-
-class FullResult(EndResult):
-    """Result of a search in ``full`` mode (``src/pyopal/lib.pyx:884-1119``)."""
-
-    __slots__ = ()
-
-    def __init__(self, target_index: int, score: int, query_end: int, target_end: int,
-                 query_start: int, target_start: int, query_length: int, target_length: int,
-                 alignment: str):
-        if alignment is None:
-            raise TypeError("Argument 'alignment' must not be None")
-        super().__init__(target_index, score, query_end, target_end)
-        self._query_length = query_length
-        self._target_length = target_length
-        self._query_start = query_start
-        self._target_start = target_start
-        self._ops = bytes(_OPAL_ALIGNMENT_OPERATION[x] for x in alignment)
-
-    def __repr__(self):
-        return (f"{type(self).__name__}({self.target_index}, score={self.score!r}, "
-                f"query_end={self.query_end!r}, target_end={self.target_end!r}, "
-                f"query_start={self.query_start!r}, target_start={self.target_start!r}, "
-                f"query_length={self.query_length!r}, target_length={self.target_length!r}, "
-                f"alignment={self.alignment!r})")
-
-    def __reduce__(self):
-        return (type(self), (self.target_index, self.score, self.query_end, self.target_end,
-                             self.query_start, self.target_start, self.query_length,
-                             self.target_length, self.alignment))
-
-    @property
-    def query_start(self) -> int:
-        assert self._query_start >= 0
-        return self._query_start
-
-    @property
-    def target_start(self) -> int:
-        assert self._target_start >= 0
-        return self._target_start
-
-    @property
-    def query_length(self) -> int:
-        assert self._query_length >= 0
-        return self._query_length
-
-    @property
-    def target_length(self) -> int:
-        assert self._target_length >= 0
-        return self._target_length
-
-    @property
-    def alignment(self) -> str:
-        """Operations as a string over ``MDIX`` (D: query residue against a gap,
-        I: target residue against a gap)."""
-        return (self._ops or b"").translate(_OPS_TO_TEXT).decode("ascii")
-
-    def cigar(self) -> typing.Optional[str]:
-        """CIGAR string in SAM convention (``op % 3`` -> ``M, I, D``)."""
-        ops = self._ops
-        if not ops:
-            return None
-        symbols = "MID"
-        chunks = []
-        count = 0
-        current = ops[0] % 3
-        for op in ops:
-            symbol = op % 3
-            if symbol == current:
-                count += 1
-            else:
-                chunks.append(f"{count}{symbols[current]}")
-                current = symbol
-                count = 1
-        chunks.append(f"{count}{symbols[current]}")
-        return "".join(chunks)
-
-    def identity(self) -> float:
-        assert self._ops is not None
-        matches = np.float32(self._ops.count(0))
-        mismatches = self._ops.count(3)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            return float(matches / np.float32(matches + mismatches))
-
-    def coverage(self, reference: str = "query") -> float:
-        assert self._ops is not None
-        if reference == "query":
-            reflength = self._query_length
-            length = self._query_end + 1 - self._query_start
-            operation = 1
-        elif reference == "target":
-            reflength = self._target_length
-            length = self._target_end + 1 - self._target_start
-            operation = 2
-        else:
-            raise ValueError(f"Invalid coverage reference: {reference!r}")
-        # edge operations that are gaps in the reference do not cover it
-        for op in self._ops:
-            if op != operation:
-                break
-            length -= 1
-        for op in reversed(self._ops):
-            if op != operation:
-                break
-            length -= 1
-        return 0.0 if length < 0 else float(np.float32(length) / np.float32(reflength))
-
+# Cython, like the reference's (src/pyopal/lib.pyx:783-1119): see _results.pyx
+try:
+    from ._results import EndResult, FullResult, ScoreResult  # noqa: E402
+except ImportError as err:  # pragma: no cover
+    raise ImportError(
+        "pyopal_amd._results is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C pyopal_amd/csrc`)") from err
 
 _RESULT_TYPES = {"score": ScoreResult, "end": EndResult, "full": FullResult}
 

@@ -11,10 +11,8 @@ import typing
 
 import numpy as np
 
-from .. import _capi
+from .. import _capi, _results
 from ..lib import (UINT32_MAX, BaseDatabase, EndResult, FullResult, ScoreResult, _int_matrix_array)
-
-_new = object.__new__
 
 
 def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, algorithm: int,
@@ -57,48 +55,12 @@ def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, 
         raise ValueError("database and score matrix have different alphabets")
     out = mirror.search(query, matrix, gap_open, gap_extend, mode_name, algo_name, start, end)
 
-    scores = out["score"].tolist()
-    indices = range(start, end)
-    results: typing.List[ScoreResult] = []
-    append = results.append
+    scores = np.ascontiguousarray(out["score"], dtype=np.int32)
     if result_type is ScoreResult:
-        for j, s in zip(indices, scores):
-            r = _new(ScoreResult)
-            r._target_index = j
-            r._score = s
-            r._score_set = True
-            append(r)
-        return results
-    end_q = out["end_q"].tolist()
-    end_t = out["end_t"].tolist()
+        return _results.score_results(start, scores)
     if result_type is EndResult:
-        for j, s, eq, et in zip(indices, scores, end_q, end_t):
-            r = _new(EndResult)
-            r._target_index = j
-            r._score = s
-            r._score_set = True
-            r._query_end = eq
-            r._target_end = et
-            append(r)
-        return results
-    start_q = out["start_q"].tolist()
-    start_t = out["start_t"].tolist()
-    lengths = database._get_lengths()
-    qlen = len(encoded)
-    ops_all = out["aln_flat"].tobytes()
-    ops_off = out["aln_off"].tolist()
-    for k, j in enumerate(indices):
-        r = FullResult.__new__(FullResult)
-        r._target_index = j
-        r._score = scores[k]
-        r._score_set = True
-        r._query_end = end_q[k]
-        r._target_end = end_t[k]
-        r._query_start = start_q[k]
-        r._target_start = start_t[k]
-        r._ops = ops_all[ops_off[k]:ops_off[k + 1]]
-        # recorded so that the coverage can be computed later (pyx.in:95-99)
-        r._query_length = qlen
-        r._target_length = int(lengths[j])
-        append(r)
-    return results
+        return _results.end_results(start, scores, out["end_q"], out["end_t"])
+    # query and target lengths are recorded so that the coverage can be computed later
+    # (pyx.in:95-99)
+    return _results.full_results(start, scores, out["end_q"], out["end_t"], out["start_q"], out["start_t"],
+                                 len(encoded), database._get_lengths(), out["aln_flat"], out["aln_off"])
