@@ -32,6 +32,7 @@
  *   H[i][j] = max(H[i-1][j-1] + S[q_i][t_j], E[i][j], F[i][j])   (SW: and 0)
  * a gap of length n costs open + (n-1)*ext (pinned by _align.py:106-111).
  * Borders:  NW  H[-1][j] = -(open + j*ext), H[i][-1] = -(open + i*ext)
+ *               (-(k+1)*open when open < ext: k+1 one-residue gaps are cheaper)
  *           HW  H[-1][j] = 0,               H[i][-1] = -(open + i*ext)
  *           OV  both 0;  SW both 0 and H floored at 0.
  * Answer:   NW last cell; HW max of last query row; OV max of last row and
@@ -45,6 +46,9 @@
  *           prefixes q[0..qe], t[0..te] under NW borders (the alignment is
  *           anchored on the end cell); region all cells for SW, last row for
  *           HW, last row and last column for OV.
+ *           When every substitution is worse than gapping, the HW / OV optimum can
+ *           be a single gap over one sequence only; the other sequence then has an
+ *           empty span (start = end + 1) and the alignment is all DEL or all INS.
  * Traceback: global alignment of q[qs..qe] with t[ts..te], walked back from
  *           the end cell; on ties diagonal first (pinned, lib.pyx:1006-1010),
  *           then the target-consuming gap (INS), then the query-consuming gap
@@ -86,8 +90,12 @@ typedef struct {
 static inline int sv(const seqview* s, int k) { return s->p[(long)k * s->step]; }
 
 static inline int border(int gap, int k, int open, int ext) {
-    /* value of a border cell that is k (0-based) residues into a border gap */
-    return gap ? -(open + k * ext) : 0;
+    /* value of a border cell that is k (0-based) residues into a border gap: one gap of
+     * k + 1 residues, or, when opening is cheaper than extending (open < ext), k + 1
+     * gaps of one residue, which is what the recurrence itself does inside the matrix */
+    if (!gap) return 0;
+    long one = open + (long)k * ext, many = (long)(k + 1) * open;
+    return -(int)(one < many ? one : many);
 }
 
 /*
@@ -177,12 +185,12 @@ static int traceback(const unsigned char* q, int n, const unsigned char* t, int 
     AT(H, 0, 0) = 0;
     AT(E, 0, 0) = AT(F, 0, 0) = NEG_INF;
     for (int j = 1; j <= m; j++) {
-        AT(H, 0, j) = -(open + (j - 1) * ext);
+        AT(H, 0, j) = border(1, j - 1, open, ext);
         AT(E, 0, j) = AT(H, 0, j);
         AT(F, 0, j) = NEG_INF;
     }
     for (int i = 1; i <= n; i++) {
-        AT(H, i, 0) = -(open + (i - 1) * ext);
+        AT(H, i, 0) = border(1, i - 1, open, ext);
         AT(F, i, 0) = AT(H, i, 0);
         AT(E, i, 0) = NEG_INF;
         for (int j = 1; j <= m; j++) {
@@ -266,7 +274,23 @@ int oracleAlignPair(const unsigned char* query, int Q, const unsigned char* targ
         int rs, ri, rj;
         dp_pass(&rq, qe + 1, &rt, te + 1, open, ext, S, A, &rr, &rs, &ri, &rj, &ovf);
         if (ovf) return OPAL_ERR_OVERFLOW;
-        if (rs != score) return MIOPAL_ERR_INTERNAL;
+        if (rs != score) {
+            /* Degenerate optimum: the best HW / OV "alignment" is one gap that consumes
+             * residues of one sequence only (every substitution is worse than gapping).
+             * Anchored on the end cell that is a border cell of the reversed problem:
+             * the whole query piece gapped with no target residue (border of the last
+             * row), or, for OV, the whole target piece gapped with no query residue
+             * (border of the last column). The empty side gets start = end + 1. */
+            if (mode != OPAL_MODE_SW && score == border(1, qe, open, ext)) {
+                ri = qe;
+                rj = -1;
+            } else if (mode == OPAL_MODE_OV && score == border(1, te, open, ext)) {
+                ri = -1;
+                rj = te;
+            } else {
+                return MIOPAL_ERR_INTERNAL;
+            }
+        }
         qs = qe - ri;
         ts = te - rj;
     }

@@ -138,6 +138,14 @@ hipError_t launchScatterEnds(const int32_t* viewEndI, const int32_t* viewEndJ, c
                              int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ,
                              hipStream_t stream);
 
+// Value of a penalised border cell k (0-based) residues into the border: one gap of k + 1
+// residues or, when opening is cheaper than extending, k + 1 one-residue gaps (what the
+// recurrence does inside the matrix). Same definition as oracle/opal_oracle.c.
+__host__ __device__ inline int borderGap(int k, int open, int ext) {
+    const long long one = open + (long long)k * ext, many = (long long)(k + 1) * open;
+    return -(int)(one < many ? one : many);
+}
+
 inline int packRules(const DpRules& r) {
     return (r.topGap ? 1 : 0) | (r.leftGap ? 2 : 0) | (r.floor0 ? 4 : 0) | (r.region << 4);
 }

@@ -1008,11 +1008,23 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         for (size_t x = 0; x < live.size(); ++x) {
             const int64_t k = live[x];
             const size_t o = onDevice ? (size_t)k : x;
-            if (hs[o] != score[k] || hi[o] < 0 || hj[o] < 0)
-                return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
-                            (long long)(start + k));
-            startQuery[k] = endQuery[k] - hi[o];
-            startTarget[k] = endTarget[k] - hj[o];
+            int ri = hi[o], rj = hj[o];
+            if (hs[o] != score[k] || ri < 0 || rj < 0) {
+                // degenerate optimum (oracle/opal_oracle.c): one gap over one sequence only,
+                // i.e. a border cell of the reversed problem; the other sequence's span is empty
+                if (mode != OPAL_MODE_SW && score[k] == borderGap(endQuery[k], gapOpen, gapExt)) {
+                    ri = endQuery[k];
+                    rj = -1;
+                } else if (mode == OPAL_MODE_OV && score[k] == borderGap(endTarget[k], gapOpen, gapExt)) {
+                    ri = -1;
+                    rj = endTarget[k];
+                } else {
+                    return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
+                                (long long)(start + k));
+                }
+            }
+            startQuery[k] = endQuery[k] - ri;
+            startTarget[k] = endTarget[k] - rj;
         }
     }
 

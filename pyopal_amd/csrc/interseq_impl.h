@@ -225,10 +225,10 @@ void interseq_kernel(InterseqArgs a) {
     const int region = kRegions ? a.region : (int)kAllCells;
     const int open = a.gapOpen, ext = a.gapExt;
     // value of a border cell k residues into a border (the other index is -1); the shifted
-    // flavour stores X + (i + j) * ext, which makes a penalised border constant
+    // flavour stores X + (i + j) * ext (the other index is -1 here)
     auto border = [&](bool gap, int k) -> int {
-        if (Arith::kDiag) return gap ? -(open + ext) : (k - 1) * ext;
-        return gap ? -(open + k * ext) : 0;
+        const int v = gap ? borderGap(k, open, ext) : 0;
+        return Arith::kDiag ? v + (k - 1) * ext : v;
     };
     // shift a stored value of cell (i, j) back to its true value
     auto unshift = [&](uint32_t v, int i, int j) -> uint32_t {

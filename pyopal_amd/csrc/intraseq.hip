@@ -60,9 +60,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             const bool rowActive = i < Q;
             const int qres = rowActive ? qptr[(int64_t)i * job.qStep] : 0;
             const int* srow = smat + qres * kMatStride;
-            int hLeft = leftGap ? -(open + i * ext) : 0;  // H[i][-1]
+            int hLeft = leftGap ? borderGap(i, open, ext) : 0;  // H[i][-1]
             int eLeft = kNegInf;
-            int hDiag = (i == 0) ? 0 : (leftGap ? -(open + (i - 1) * ext) : 0);  // H[i-1][-1]
+            int hDiag = (i == 0) ? 0 : (leftGap ? borderGap(i - 1, open, ext) : 0);  // H[i-1][-1]
             int hCur = 0, fCur = kNegInf;
             const int2* bin = a.boundary[(s + 1) & 1] + job.wsOff;
             int2* bout = a.boundary[s & 1] + job.wsOff;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     // DP stage of step k
                     int hTop = bH, fTop = bF;
                     if (s == 0) {
-                        hTop = topGap ? -(open + k * ext) : 0;
+                        hTop = topGap ? borderGap(k, open, ext) : 0;
                         fTop = kNegInf;
                     } else {
                         bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     } else if (!floor0) {
         // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
         best = 0;
-        if (Q > 0) best = leftGap ? -(open + (Q - 1) * ext) : 0;
-        if (L > 0) best = topGap ? -(open + (L - 1) * ext) : 0;
+        if (Q > 0) best = leftGap ? borderGap(Q - 1, open, ext) : 0;
+        if (L > 0) best = topGap ? borderGap(L - 1, open, ext) : 0;
     }
     if (lane == 0) {
         a.score[job.out] = best;
