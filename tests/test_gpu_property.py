@@ -70,3 +70,47 @@ def test_random_cases_match_the_checker(capi, case):
         np.testing.assert_array_equal(gpu["start_t"], ref["start_t"])
         for a, b in zip(gpu["aln"], ref["aln"]):
             assert a.tolist() == b.tolist()
+
+
+@st.composite
+def long_cases(draw):
+    """Fewer, larger cases: targets around the packed / long-target boundary (8192),
+    several strips, scores that leave the half-float and int16 ranges."""
+    seed = draw(st.integers(0, 2**31 - 1))
+    rng = np.random.default_rng(seed)
+    A = draw(st.sampled_from([4, 24]))
+    qlen = draw(st.sampled_from([40, 64, 65, 130, 257, 520]))
+    kind = draw(st.sampled_from(["random", "homolog", "boundary"]))
+    query = rng.integers(0, A, size=qlen).astype(np.uint8)
+    if kind == "random":
+        lengths = rng.integers(1, 3000, size=draw(st.integers(1, 6)))
+        seqs = [rng.integers(0, A, size=int(L)).astype(np.uint8) for L in lengths]
+    elif kind == "homolog":
+        # many copies of the query with few changes: high scores, long diagonal runs
+        reps = draw(st.integers(1, 12))
+        base = np.tile(query, reps)
+        seqs = []
+        for _ in range(draw(st.integers(1, 4))):
+            s = base.copy()
+            s[rng.integers(0, len(s), size=max(1, len(s) // 50))] = rng.integers(0, A)
+            seqs.append(s)
+        seqs.append(rng.integers(0, A, size=int(rng.integers(1, 500))).astype(np.uint8))
+    else:
+        lengths = [8190, 8192, 8193, int(rng.integers(1, 200))]
+        seqs = [rng.integers(0, A, size=L).astype(np.uint8) for L in lengths[:draw(st.integers(1, 4))]]
+    match = draw(st.sampled_from([2, 5, 11]))
+    matrix = rng.integers(-6, 3, size=(A, A)).astype(np.int32)
+    matrix[np.arange(A), np.arange(A)] = match
+    gap_open = draw(st.sampled_from([1, 3, 11]))
+    gap_ext = draw(st.sampled_from([0, 1, 2]))
+    mode = draw(st.sampled_from(["score", "end", "full"]))
+    algo = draw(st.sampled_from(["nw", "hw", "ov", "sw"]))
+    return A, matrix, query, seqs, gap_open, gap_ext, mode, algo
+
+
+@settings(max_examples=120, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow,
+                                 HealthCheck.data_too_large])
+@given(case=long_cases())
+def test_random_long_cases_match_the_checker(capi, case):
+    test_random_cases_match_the_checker.hypothesis.inner_test(capi, case)
