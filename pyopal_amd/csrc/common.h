@@ -83,7 +83,8 @@ struct WalkArgs {
     const uint8_t* query;
     const uint8_t* dirs;
     uint8_t* ops;             // per job: buffer of qLen + tLen bytes, filled from the back
-    const int64_t* opsOff;    // [nJobs + 1]
+    const int64_t* opsOff;    // [nJobs + 1], or null: job k owns the fixed slot k * opsSlot
+    int64_t opsSlot;
     int32_t* opsLen;
 };
 
@@ -128,6 +129,14 @@ hipError_t launchInterseqSignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, 
 hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
+hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* score, const int32_t* endQ,
+                            const int32_t* endT, const int32_t* rScore, const int32_t* rI, const int32_t* rJ,
+                            int32_t* startQ, int32_t* startT, int* mismatch, hipStream_t stream);
+hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
+                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
+                           hipStream_t stream);
+hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
+                           const int64_t* outOff, uint8_t* out, hipStream_t stream);
 hipError_t launchReverseJobs(int n, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
                              int rules, PairJob* jobs, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);

@@ -85,7 +85,7 @@ constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent st
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kSlots
 };
 
 struct Workspace {
@@ -495,7 +495,8 @@ struct Search {
 
     // Same with a job list that already sits in HBM and needs no strip-boundary workspace
     // (every query piece fits one 64-row strip).
-    int runDeviceJobs(const PairJob* d_jobs, int nJobs, int32_t* d_score, int32_t* d_endI, int32_t* d_endJ) {
+    int runDeviceJobs(const PairJob* d_jobs, int nJobs, int32_t* d_score, int32_t* d_endI, int32_t* d_endJ,
+                      bool trace = false, uint8_t* d_dirs = nullptr) {
         if (nJobs <= 0) return 0;
         RC_TRY(ensurePairInputs());
         IntraseqArgs a{};
@@ -510,7 +511,8 @@ struct Search {
         a.score = d_score;
         a.endI = d_endI;
         a.endJ = d_endJ;
-        HIP_TRY(launchIntraseq(a, false, stream));
+        a.dirs = d_dirs;
+        HIP_TRY(launchIntraseq(a, trace, stream));
         return 0;
     }
 
@@ -947,9 +949,126 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     pt.mark("score/end pass + D2H");
     if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
 
-    // ---- start locations: reversed prefixes anchored on the end cell ----------
     DpRules fr;
     RC_TRY(s.rulesFor(mode, &fr));
+
+    // ---- queries of one strip: the rest of the pipeline stays in HBM ---------------
+    // (start cells, traceback jobs, direction bytes and operations are produced and
+    // consumed on the device; the host only prefix-sums the alignment lengths)
+    {
+        const int64_t slotDir = (db->maxLen + kLanes - 1) * kLanes;  // direction bytes of one pair
+        const int64_t slotOps = queryLength + db->maxLen;            // operations of one pair
+        const bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
+                                n * slotOps <= (8ll << 30) && !getenv("MIOPAL_HOST_TRACEBACK");
+        if (deviceFull) {
+            std::vector<uint8_t> localOps;
+            std::vector<int64_t> localOff;
+            std::vector<uint8_t>* outOps = flatOps;
+            int64_t* outOff = flatOff;
+            if (!flat) {
+                localOff.assign((size_t)n + 1, 0);
+                outOps = &localOps;
+                outOff = localOff.data();
+            }
+            void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *poff, *pcompact, *pts;
+            RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
+            RC_TRY(ws->get(kStartQ, (size_t)n * sizeof(int32_t), &psq));
+            RC_TRY(ws->get(kStartT, (size_t)n * sizeof(int32_t), &pst));
+            RC_TRY(ws->get(kMismatch, sizeof(int), &pmis));
+            RC_TRY(ws->get(kOpsLen, (size_t)n * sizeof(int32_t), &plen));
+            RC_TRY(ws->get(kOpsOff, (size_t)n * sizeof(int64_t), &poff));
+            RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
+            RC_TRY(ws->get(kRScore, (size_t)n * sizeof(int32_t), &rs));
+            HIP_TRY(hipMemsetAsync(pmis, 0, sizeof(int), stream));
+            if (mode != OPAL_MODE_NW) {
+                RC_TRY(ws->get(kRI, (size_t)n * sizeof(int32_t), &ri));
+                RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
+                const DpRules rr{1, 1, 0, fr.region};
+                HIP_TRY(launchReverseJobs((int)n, (const int32_t*)pi, (const int32_t*)pj, db->d_offsets + start,
+                                          packRules(rr), (PairJob*)pjobs, stream));
+                RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
+            }
+            HIP_TRY(launchStartCells((int)n, mode, gapOpen, gapExt, (const int32_t*)ps, (const int32_t*)pi,
+                                     (const int32_t*)pj, (const int32_t*)rs, (const int32_t*)ri, (const int32_t*)rj,
+                                     (int32_t*)psq, (int32_t*)pst, (int*)pmis, stream));
+            pt.mark("start cells (enqueued)");
+            // traceback in batches of whole direction slots
+            const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n, kDirBudget * 4 / slotDir));
+            void *pd, *pslots;
+            RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
+            RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
+            RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
+            std::unique_ptr<int32_t[]> lens(new int32_t[(size_t)n]);
+            std::unique_ptr<int64_t[]> offs(new int64_t[(size_t)n]);
+            int64_t total = 0;
+            outOff[0] = 0;
+            for (int64_t b0 = 0; b0 < n; b0 += batch) {
+                const int nb = (int)std::min<int64_t>(batch, n - b0);
+                PairJob* jobs = (PairJob*)pjobs + b0;
+                HIP_TRY(launchTraceJobs(nb, packRules(DpRules{1, 1, 0, kLastCell}), (const int32_t*)psq + b0,
+                                        (const int32_t*)pst + b0, (const int32_t*)pi + b0, (const int32_t*)pj + b0,
+                                        db->d_offsets + start + b0, slotDir, jobs, stream));
+                // job.out is relative to the batch: offset the score pointer
+                RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
+                WalkArgs wa{};
+                wa.jobs = jobs;
+                wa.nJobs = nb;
+                wa.residues = db->d_residues;
+                wa.query = s.d_query;
+                wa.dirs = (const uint8_t*)pd;
+                wa.ops = (uint8_t*)pslots;
+                wa.opsOff = nullptr;
+                wa.opsSlot = slotOps;
+                wa.opsLen = (int32_t*)plen + b0;
+                HIP_TRY(launchWalk(wa, stream));
+                RC_TRY(ws->stageDownload(lens.get() + b0, (int32_t*)plen + b0, (size_t)nb * sizeof(int32_t)));
+                RC_TRY(ws->finishDownloads());
+                for (int k = 0; k < nb; ++k) {
+                    offs[(size_t)(b0 + k)] = total;
+                    total += lens[(size_t)(b0 + k)];
+                    outOff[b0 + k + 1] = total;
+                }
+                RC_TRY(upload((int64_t*)poff + b0, offs.get() + b0, (size_t)nb, stream));
+                HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
+                                        (const int64_t*)poff + b0, (uint8_t*)pcompact, stream));
+            }
+            pt.mark("traceback batches");
+            // results back to the host
+            int mismatch = 0;
+            std::unique_ptr<int32_t[]> tscore(new int32_t[(size_t)n]);
+            RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
+            RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
+            RC_TRY(ws->stageDownload(tscore.get(), pts, (size_t)n * sizeof(int32_t)));
+            RC_TRY(ws->stageDownload(&mismatch, pmis, sizeof(int)));
+            outOps->resize((size_t)total);
+            RC_TRY(ws->stageDownload(outOps->data(), pcompact, (size_t)total));
+            RC_TRY(ws->finishDownloads());
+            pt.mark("results D2H");
+            if (mismatch)
+                return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
+                            (long long)(start + mismatch - 1));
+            for (int64_t k = 0; k < n; ++k)
+                if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k])
+                    return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
+                                tscore[(size_t)k], score[k], (long long)(start + k));
+            if (!flat) {
+                for (int64_t k = 0; k < n; ++k) {
+                    const int64_t len = outOff[k + 1] - outOff[k];
+                    alignment[k] = nullptr;
+                    alignmentLength[k] = (int)len;
+                    if (endQuery[k] < 0 || endTarget[k] < 0) continue;
+                    unsigned char* buf = (unsigned char*)malloc((size_t)std::max<int64_t>(len, 1));
+                    if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+                    memcpy(buf, outOps->data() + outOff[k], (size_t)len);
+                    alignment[k] = buf;
+                }
+            }
+            pt.mark("host copy-out");
+            return 0;
+        }
+    }
+
+    // ---- start locations: reversed prefixes anchored on the end cell ----------
     for (int64_t k = 0; k < n; ++k) {
         startQuery[k] = startTarget[k] = -1;
         if (flat) {

@@ -190,8 +190,8 @@ __global__ void walk_kernel(WalkArgs a) {
     const uint8_t* dirs = a.dirs + job.dirOff;
     const uint8_t* q = a.query + job.qOff;
     const uint8_t* t = a.residues + job.tOff;
-    uint8_t* ops = a.ops + a.opsOff[idx];
-    int64_t pos = a.opsOff[idx + 1] - a.opsOff[idx];
+    uint8_t* ops = a.opsOff ? a.ops + a.opsOff[idx] : a.ops + (int64_t)idx * a.opsSlot;
+    int64_t pos = a.opsOff ? a.opsOff[idx + 1] - a.opsOff[idx] : a.opsSlot;
     int i = n - 1, j = m - 1, state = 0, len = 0;
     while (i >= 0 || j >= 0) {
         if (i < 0) { ops[--pos] = 2; --j; ++len; continue; }
@@ -241,6 +241,103 @@ __global__ void reverse_jobs_kernel(int n, const int32_t* endQ, const int32_t* e
         j.qLen = qe + 1;
     }
     jobs[k] = j;
+}
+
+// ---- full-mode pipeline kept in HBM (queries that fit one 64-row strip) --------------
+// Start cells from the reversed-prefix pass, including the degenerate optimum of HW / OV
+// (oracle/opal_oracle.c): one gap over one sequence only = a border cell of the reversed
+// problem. Slots whose reverse score disagrees raise *mismatch.
+__global__ void start_cells_kernel(int n, int mode, int open, int ext, const int32_t* score,
+                                   const int32_t* endQ, const int32_t* endT, const int32_t* rScore,
+                                   const int32_t* rI, const int32_t* rJ, int32_t* startQ,
+                                   int32_t* startT, int* mismatch) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int qe = endQ[k], te = endT[k];
+    int sq = -1, st = -1;
+    if (qe >= 0 && te >= 0) {
+        if (mode == 0 /* NW */) {
+            sq = 0;
+            st = 0;
+        } else {
+            int ri = rI[k], rj = rJ[k];
+            if (rScore[k] != score[k] || ri < 0 || rj < 0) {
+                if (mode != 3 /* SW */ && score[k] == borderGap(qe, open, ext)) {
+                    ri = qe;
+                    rj = -1;
+                } else if (mode == 2 /* OV */ && score[k] == borderGap(te, open, ext)) {
+                    ri = -1;
+                    rj = te;
+                } else {
+                    atomicExch(mismatch, k + 1);
+                    ri = qe;
+                    rj = te;
+                }
+            }
+            sq = qe - ri;
+            st = te - rj;
+        }
+    }
+    startQ[k] = sq;
+    startT[k] = st;
+}
+
+// Traceback jobs on the [start..end] rectangles; job k owns direction slot k.
+__global__ void trace_jobs_kernel(int n, int rules, const int32_t* startQ, const int32_t* startT,
+                                  const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
+                                  int64_t dirStride, PairJob* jobs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    PairJob j{};
+    j.out = k;
+    j.rules = rules;
+    j.tStep = 1;
+    j.qStep = 1;
+    j.dirOff = (int64_t)k * dirStride;
+    if (endQ[k] >= 0 && endT[k] >= 0) {
+        j.tOff = offsets[k] + startT[k];
+        j.tLen = endT[k] - startT[k] + 1;
+        j.qOff = startQ[k];
+        j.qLen = endQ[k] - startQ[k] + 1;
+    }
+    jobs[k] = j;
+}
+
+// Pack the operations (written from the back of fixed-size slots) into one buffer.
+__global__ void gather_ops_kernel(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
+                                  const int64_t* outOff, uint8_t* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int len = lens[k];
+    const uint8_t* src = slots + (int64_t)(k + 1) * slotBytes - len;
+    uint8_t* dst = out + outOff[k];
+    for (int i = 0; i < len; ++i) dst[i] = src[i];
+}
+
+hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* score, const int32_t* endQ,
+                            const int32_t* endT, const int32_t* rScore, const int32_t* rI, const int32_t* rJ,
+                            int32_t* startQ, int32_t* startT, int* mismatch, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(start_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, mode, open, ext, score,
+                       endQ, endT, rScore, rI, rJ, startQ, startT, mismatch);
+    return hipGetLastError();
+}
+
+hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
+                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
+                           hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trace_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, rules, startQ, startT,
+                       endQ, endT, offsets, dirStride, jobs);
+    return hipGetLastError();
+}
+
+hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
+                           const int64_t* outOff, uint8_t* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_ops_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, slots, slotBytes, lens,
+                       outOff, out);
+    return hipGetLastError();
 }
 
 hipError_t launchReverseJobs(int n, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
