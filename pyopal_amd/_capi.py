@@ -146,6 +146,18 @@ def _ptr(a: typing.Optional[np.ndarray]):
     return None if a is None else a.ctypes.data
 
 
+class _MallocBytes:
+    """Owner of a buffer returned by the C ABI; numpy arrays made from it keep it alive."""
+
+    def __init__(self, address: int, size: int):
+        self._address = address
+        self.__array_interface__ = {"data": (address, False), "shape": (size,), "typestr": "|u1",
+                                    "version": 3}
+
+    def __del__(self):
+        _libc.free(ctypes.c_void_p(self._address))
+
+
 class _LazyAlignments:
     """List-like view of the per-target operation arrays inside the flat buffer."""
 
@@ -229,13 +241,11 @@ class DeviceDatabase:
             out.update(end_t=et, end_q=eq)
         if st == 2:
             total = int(aoff[-1]) if n else 0
-            if ops_ptr.value and total:
-                flat = np.frombuffer((ctypes.c_ubyte * total).from_address(ops_ptr.value),
-                                     dtype=np.uint8).copy()
+            if ops_ptr.value:
+                # the array takes the malloc'ed buffer over (freed with the array) - no copy
+                flat = np.asarray(_MallocBytes(ops_ptr.value, total))
             else:
                 flat = np.zeros(0, dtype=np.uint8)
-            if ops_ptr.value:
-                _libc.free(ops_ptr)
             out.update(start_t=s_t, start_q=s_q, aln_flat=flat, aln_off=aoff,
                        aln=_LazyAlignments(flat, aoff))
         return out

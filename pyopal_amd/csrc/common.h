@@ -53,12 +53,14 @@ struct PairJob {
     int32_t qOff;    // index of the first query residue visited
     int32_t qLen;
     int32_t qStep;
-    int32_t rules;   // bit0 topGap, bit1 leftGap, bit2 floor0, bits 4..5 region
+    int32_t rules;   // bit0 topGap, bit1 leftGap, bit2 floor0, bits 4..5 region, bit6 stop
     int64_t wsOff;   // int2 elements into the strip-boundary workspace (per buffer)
     int64_t dirOff;  // bytes into the direction workspace (trace only)
     int32_t out;     // result slot
-    int32_t pad;
+    int32_t stop;    // with rules bit6 (single-strip pairs): the optimum is known to be `stop`,
+                     // the scan ends with the first column that reaches it
 };
+constexpr int kRuleStop = 0x40;
 
 struct IntraseqArgs {
     const PairJob* jobs;
@@ -135,9 +137,11 @@ hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* s
 hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
                            const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
                            hipStream_t stream);
+// blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
-                           const int64_t* outOff, uint8_t* out, hipStream_t stream);
-hipError_t launchReverseJobs(int n, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
+                           int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,
+                           hipStream_t stream);
+hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
                              int rules, PairJob* jobs, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,

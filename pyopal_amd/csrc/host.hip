@@ -19,6 +19,8 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <sys/mman.h>
+#include <thread>
 #include <vector>
 
 #include "../../include/miopal.h"
@@ -79,13 +81,61 @@ constexpr int64_t kDirBudget = 2ll << 30;  // bytes of direction workspace per t
 constexpr int64_t kInt32Safe = 1ll << 29;
 constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
 
+// malloc-backed byte buffer: grows without zero-filling, and its storage can be handed to the
+// caller of the C ABI (who frees it with free()).
+struct HostBytes {
+    uint8_t* data = nullptr;
+    size_t size = 0, cap = 0;
+    HostBytes() = default;
+    HostBytes(const HostBytes&) = delete;
+    HostBytes& operator=(const HostBytes&) = delete;
+    ~HostBytes() { free(data); }
+    bool reserve(size_t want) {
+        if (want <= cap) return true;
+        want = std::max(want, cap + cap / 2);
+        if (!data && want >= (8u << 20)) {
+            // a large result buffer is written once, front to back: ask for huge pages so that
+            // first touch costs tens of faults instead of tens of thousands
+            void* p = nullptr;
+            if (posix_memalign(&p, 2u << 20, want) == 0) {
+                madvise(p, want, MADV_HUGEPAGE);
+                data = (uint8_t*)p;
+                cap = want;
+                return true;
+            }
+        }
+        uint8_t* p = (uint8_t*)realloc(data, want);
+        if (!p) return false;
+        data = p;
+        cap = want;
+        return true;
+    }
+    bool resize(size_t n) {
+        if (!reserve(std::max<size_t>(n, 1))) return false;
+        size = n;
+        return true;
+    }
+    bool append(const uint8_t* src, size_t n) {
+        if (!reserve(size + n)) return false;
+        memcpy(data + size, src, n);
+        size += n;
+        return true;
+    }
+    uint8_t* release() {
+        uint8_t* p = data;
+        data = nullptr;
+        size = cap = 0;
+        return p;
+    }
+};
+
 // ---------------------------------------------------------------------------
 // per-stream workspace: growable device buffers reused in stream order
 // ---------------------------------------------------------------------------
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSlots
 };
 
 struct Workspace {
@@ -107,10 +157,29 @@ struct Workspace {
     struct Pending { void* dst; size_t off, bytes; };
     std::vector<Pending> pending;
 
+    // Large results land in pages the caller has not touched yet; a few threads fault them in
+    // side by side.
+    static void copyOut(void* dst, const char* src, size_t bytes) {
+        constexpr size_t kPiece = 4u << 20;
+        if (bytes < 2 * kPiece) {
+            memcpy(dst, src, bytes);
+            return;
+        }
+        const int nThreads = (int)std::min<size_t>(4, bytes / kPiece);
+        const size_t share = ((bytes / nThreads) + 4095) & ~(size_t)4095;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nThreads; ++t) {
+            const size_t lo = share * t, hi = std::min(bytes, lo + share);
+            if (lo < hi) pool.emplace_back([=] { memcpy((char*)dst + lo, src + lo, hi - lo); });
+        }
+        memcpy(dst, src, std::min(bytes, share));
+        for (auto& th : pool) th.join();
+    }
+
     int finishDownloads() {
         if (pending.empty()) return 0;
         HIP_TRY(hipStreamSynchronize(stream));
-        for (const Pending& p : pending) memcpy(p.dst, (const char*)pinned + p.off, p.bytes);
+        for (const Pending& p : pending) copyOut(p.dst, (const char*)pinned + p.off, p.bytes);
         pending.clear();
         pinnedUsed = 0;
         return 0;
@@ -910,7 +979,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                       const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
                       int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
                       int* startQuery, unsigned char** alignment, int* alignmentLength,
-                      std::vector<uint8_t>* flatOps, int64_t* flatOff) {
+                      HostBytes* flatOps, int64_t* flatOff) {
     RC_TRY(validate(db, query, queryLength, scoreMatrix, alphabetLength, searchType, mode, start, end));
     const int64_t n = end - start;
     if (n == 0) return 0;
@@ -961,22 +1030,21 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         const bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
                                 n * slotOps <= (8ll << 30) && !getenv("MIOPAL_HOST_TRACEBACK");
         if (deviceFull) {
-            std::vector<uint8_t> localOps;
+            HostBytes localOps;
             std::vector<int64_t> localOff;
-            std::vector<uint8_t>* outOps = flatOps;
+            HostBytes* outOps = flatOps;
             int64_t* outOff = flatOff;
             if (!flat) {
                 localOff.assign((size_t)n + 1, 0);
                 outOps = &localOps;
                 outOff = localOff.data();
             }
-            void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *poff, *pcompact, *pts;
+            void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *pcompact, *pts;
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             RC_TRY(ws->get(kStartQ, (size_t)n * sizeof(int32_t), &psq));
             RC_TRY(ws->get(kStartT, (size_t)n * sizeof(int32_t), &pst));
             RC_TRY(ws->get(kMismatch, sizeof(int), &pmis));
             RC_TRY(ws->get(kOpsLen, (size_t)n * sizeof(int32_t), &plen));
-            RC_TRY(ws->get(kOpsOff, (size_t)n * sizeof(int64_t), &poff));
             RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
             RC_TRY(ws->get(kRScore, (size_t)n * sizeof(int32_t), &rs));
             HIP_TRY(hipMemsetAsync(pmis, 0, sizeof(int), stream));
@@ -984,7 +1052,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 RC_TRY(ws->get(kRI, (size_t)n * sizeof(int32_t), &ri));
                 RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
                 const DpRules rr{1, 1, 0, fr.region};
-                HIP_TRY(launchReverseJobs((int)n, (const int32_t*)pi, (const int32_t*)pj, db->d_offsets + start,
+                HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
+                                          db->d_offsets + start,
                                           packRules(rr), (PairJob*)pjobs, stream));
                 RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
             }
@@ -998,11 +1067,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
             RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
             RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
-            std::unique_ptr<int32_t[]> lens(new int32_t[(size_t)n]);
-            std::unique_ptr<int64_t[]> offs(new int64_t[(size_t)n]);
-            int64_t total = 0;
-            outOff[0] = 0;
-            for (int64_t b0 = 0; b0 < n; b0 += batch) {
+            const int64_t nBatches = (n + batch - 1) / batch;
+            void *pblock, *ptotals;
+            RC_TRY(ws->get(kOpsOff, (size_t)((batch + 255) / 256) * sizeof(int64_t), &pblock));
+            RC_TRY(ws->get(kOpsTotals, (size_t)(nBatches + 1) * sizeof(int64_t), &ptotals));
+            HIP_TRY(hipMemsetAsync(ptotals, 0, sizeof(int64_t), stream));
+            for (int64_t b0 = 0, b = 0; b0 < n; b0 += batch, ++b) {
                 const int nb = (int)std::min<int64_t>(batch, n - b0);
                 PairJob* jobs = (PairJob*)pjobs + b0;
                 HIP_TRY(launchTraceJobs(nb, packRules(DpRules{1, 1, 0, kLastCell}), (const int32_t*)psq + b0,
@@ -1021,29 +1091,33 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 wa.opsSlot = slotOps;
                 wa.opsLen = (int32_t*)plen + b0;
                 HIP_TRY(launchWalk(wa, stream));
-                RC_TRY(ws->stageDownload(lens.get() + b0, (int32_t*)plen + b0, (size_t)nb * sizeof(int32_t)));
-                RC_TRY(ws->finishDownloads());
-                for (int k = 0; k < nb; ++k) {
-                    offs[(size_t)(b0 + k)] = total;
-                    total += lens[(size_t)(b0 + k)];
-                    outOff[b0 + k + 1] = total;
-                }
-                RC_TRY(upload((int64_t*)poff + b0, offs.get() + b0, (size_t)nb, stream));
                 HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
-                                        (const int64_t*)poff + b0, (uint8_t*)pcompact, stream));
+                                        (int64_t*)pblock, (const int64_t*)ptotals + b, (int64_t*)ptotals + b + 1,
+                                        (uint8_t*)pcompact, stream));
             }
-            pt.mark("traceback batches");
-            // results back to the host
+            pt.mark("traceback batches (enqueued)");
+            // results back to the host: the small arrays first (they carry the total size),
+            // the operations while the host turns lengths into offsets
             int mismatch = 0;
+            int64_t total = 0;
             std::unique_ptr<int32_t[]> tscore(new int32_t[(size_t)n]);
+            std::unique_ptr<int32_t[]> lens(new int32_t[(size_t)n]);
+            RC_TRY(ws->stageDownload(&total, (const int64_t*)ptotals + nBatches, sizeof(int64_t)));
+            RC_TRY(ws->stageDownload(&mismatch, pmis, sizeof(int)));
+            RC_TRY(ws->stageDownload(lens.get(), plen, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(tscore.get(), pts, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->stageDownload(&mismatch, pmis, sizeof(int)));
-            outOps->resize((size_t)total);
-            RC_TRY(ws->stageDownload(outOps->data(), pcompact, (size_t)total));
             RC_TRY(ws->finishDownloads());
-            pt.mark("results D2H");
+            pt.mark("device pipeline + small D2H");
+            if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
+            if (!outOps->resize((size_t)total)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+            RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
+            outOff[0] = 0;
+            for (int64_t k = 0; k < n; ++k) outOff[k + 1] = outOff[k] + lens[(size_t)k];
+            if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
+            RC_TRY(ws->finishDownloads());
+            pt.mark("operations D2H");
             if (mismatch)
                 return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
                             (long long)(start + mismatch - 1));
@@ -1059,7 +1133,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     if (endQuery[k] < 0 || endTarget[k] < 0) continue;
                     unsigned char* buf = (unsigned char*)malloc((size_t)std::max<int64_t>(len, 1));
                     if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-                    memcpy(buf, outOps->data() + outOff[k], (size_t)len);
+                    memcpy(buf, outOps->data + outOff[k], (size_t)len);
                     alignment[k] = buf;
                 }
             }
@@ -1080,7 +1154,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     }
     if (flat) {
         flatOff[0] = 0;
-        flatOps->reserve((size_t)n * (size_t)std::min<int64_t>(queryLength + 16, 4096));
+        if (!flatOps->reserve((size_t)n * (size_t)std::min<int64_t>(queryLength + 16, 4096)))
+            return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
     }
     std::vector<int64_t> live;  // slots with a non-empty alignment
     for (int64_t k = 0; k < n; ++k)
@@ -1099,7 +1174,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             void* pjobs;
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             // pi / pj still hold the end locations of the forward pass (slice order)
-            HIP_TRY(launchReverseJobs((int)n, (const int32_t*)pi, (const int32_t*)pj, db->d_offsets + start,
+            HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
+                                      db->d_offsets + start,
                                       packRules(rr), (PairJob*)pjobs, stream));
             RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
         } else {
@@ -1213,7 +1289,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             const uint8_t* src = ops.get() + opsOff[x + 1] - len;
             if (flat) {
                 // jobs are visited in increasing target order, so appending keeps slice order
-                flatOps->insert(flatOps->end(), src, src + len);
+                if (!flatOps->append(src, (size_t)len)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
                 flatOff[k + 1] = len;
             } else {
                 unsigned char* buf = (unsigned char*)malloc((size_t)std::max(len, 1));
@@ -1243,7 +1319,7 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
                      const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
                      int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
                      int* startQuery, unsigned char** operations, int64_t* operationOffsets) {
-    std::vector<uint8_t> ops;
+    HostBytes ops;
     const bool full = searchType == OPAL_SEARCH_ALIGNMENT;
     if (full && !operations) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
     if (operations) *operations = nullptr;
@@ -1251,10 +1327,8 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
                       start, end, score, endTarget, endQuery, startTarget, startQuery, nullptr, nullptr,
                       full ? &ops : nullptr, full ? operationOffsets : nullptr));
     if (full && end > start) {
-        unsigned char* buf = (unsigned char*)malloc(std::max<size_t>(ops.size(), 1));
-        if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-        if (!ops.empty()) memcpy(buf, ops.data(), ops.size());
-        *operations = buf;
+        if (!ops.data && !ops.resize(0)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+        *operations = ops.release();
     }
     return 0;
 }

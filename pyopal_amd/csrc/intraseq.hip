@@ -52,7 +52,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
 
     if (Q > 0 && L > 0) {
         const int nStrips = (Q + kLanes - 1) / kLanes;
-        const int nSteps = L + kLanes - 1;
+        const int nSteps = L + kLanes - 1;  // layout of the direction bytes (walk_kernel)
+        const bool stopEnabled = (job.rules & kRuleStop) && nStrips == 1;
+        const int stopScore = job.stop;
         const uint8_t* tptr = a.residues + job.tOff;
         const uint8_t* qptr = a.query + job.qOff;
         for (int s = 0; s < nStrips; ++s) {
@@ -89,7 +91,10 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             int scCur = srow[tres];
             int tbuf = 0, bH = 0, bF = kNegInf;
 
-            for (int k0 = 0; k0 < nSteps; k0 += kLanes) {
+            // the last strip has min(Q - 64 s, 64) rows: its sweep is that much shorter
+            const int rows = min(Q - s * kLanes, kLanes);
+            int kLimit = L + rows - 1;  // wave-uniform; shrinks once the known optimum is met
+            for (int k0 = 0; k0 < kLimit; k0 += kLanes) {
                 {
                     const int kt = k0 + 1 + lane;  // residues of steps k0+1 .. k0+64
                     tbuf = kt < L ? tptr[(int64_t)kt * job.tStep] : 0;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                         bF = b.y;
                     }
                 }
-                const int kEnd = min(k0 + kLanes, nSteps);
+                const int kEnd = min(k0 + kLanes, kLimit);
                 for (int k = k0; k < kEnd; ++k) {
                     // residue stage of step k + 1
                     const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
@@ -148,6 +153,19 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     bj = take ? j : bj;
                     if (writer && valid) bout[j] = make_int2(h, f);
                     scCur = scNext;
+                    if (stopEnabled) {
+                        // First maximum of the column-major scan = the first column holding the
+                        // (known) optimum: once a lane meets it in column c, only the steps that
+                        // complete columns <= c can still change the answer.
+                        const bool hit = take && h == stopScore;
+                        if (__builtin_amdgcn_ballot_w64(hit)) {
+                            int c = hit ? j : INT32_MAX;
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1) c = min(c, __shfl_xor(c, off));
+                            kLimit = min(kLimit, __builtin_amdgcn_readfirstlane(c) + rows);
+                        }
+                        if (k + 1 >= kLimit) break;
+                    }
                 }
             }
             if (!lastStrip) __threadfence();
@@ -224,7 +242,7 @@ __global__ void walk_kernel(WalkArgs a) {
 // Jobs of the start-location pass, built where the end locations already are (HBM):
 // reversed prefixes q[0..endQ], t[0..endT] anchored on the end cell. Targets without an
 // end cell get an empty job (its outputs are ignored by the host).
-__global__ void reverse_jobs_kernel(int n, const int32_t* endQ, const int32_t* endT,
+__global__ void reverse_jobs_kernel(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT,
                                     const int64_t* offsets, int rules, PairJob* jobs) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -234,6 +252,11 @@ __global__ void reverse_jobs_kernel(int n, const int32_t* endQ, const int32_t* e
     j.rules = rules;
     j.tStep = -1;
     j.qStep = -1;
+    if (score) {
+        // the reversed problem has the same optimum as the forward one: stop at its first column
+        j.rules |= kRuleStop;
+        j.stop = score[k];
+    }
     if (qe >= 0 && te >= 0) {
         j.tOff = offsets[k] + te;
         j.tLen = te + 1;
@@ -303,14 +326,53 @@ __global__ void trace_jobs_kernel(int n, int rules, const int32_t* startQ, const
     jobs[k] = j;
 }
 
-// Pack the operations (written from the back of fixed-size slots) into one buffer.
-__global__ void gather_ops_kernel(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
-                                  const int64_t* outOff, uint8_t* out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// Pack the operations (written from the back of fixed-size slots) into one buffer, in slice
+// order. The destination of slot k is *base + (sum of lens[0..k)): block sums first, then each
+// block adds up the sums before it and scans its own 256 lengths in LDS. *next receives the
+// running total for the following batch - the host never has to see the lengths in between.
+constexpr int kGatherBlock = 256;
+
+__global__ __launch_bounds__(kGatherBlock) void ops_block_sums_kernel(int n, const int32_t* lens,
+                                                                      int64_t* blockSums) {
+    __shared__ int red[kGatherBlock];
+    const int t = threadIdx.x, k = blockIdx.x * kGatherBlock + t;
+    red[t] = k < n ? lens[k] : 0;
+    __syncthreads();
+    for (int off = kGatherBlock / 2; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    if (t == 0) blockSums[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(kGatherBlock) void gather_ops_kernel(int n, const uint8_t* slots, int64_t slotBytes,
+                                                                  const int32_t* lens, const int64_t* blockSums,
+                                                                  const int64_t* base, int64_t* next,
+                                                                  uint8_t* out) {
+    __shared__ int64_t red[kGatherBlock];
+    __shared__ int scan[kGatherBlock];
+    const int t = threadIdx.x, k = blockIdx.x * kGatherBlock + t;
+    int64_t before = 0;
+    for (int b = t; b < (int)blockIdx.x; b += kGatherBlock) before += blockSums[b];
+    red[t] = before;
+    const int len = k < n ? lens[k] : 0;
+    scan[t] = len;
+    __syncthreads();
+    for (int off = kGatherBlock / 2; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    for (int off = 1; off < kGatherBlock; off <<= 1) {
+        const int v = t >= off ? scan[t - off] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
     if (k >= n) return;
-    const int len = lens[k];
+    const int64_t dstOff = *base + red[0] + scan[t] - len;
+    if (k == n - 1) *next = dstOff + len;
     const uint8_t* src = slots + (int64_t)(k + 1) * slotBytes - len;
-    uint8_t* dst = out + outOff[k];
+    uint8_t* dst = out + dstOff;
     for (int i = 0; i < len; ++i) dst[i] = src[i];
 }
 
@@ -333,18 +395,21 @@ hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_
 }
 
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
-                           const int64_t* outOff, uint8_t* out, hipStream_t stream) {
+                           int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,
+                           hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_ops_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, slots, slotBytes, lens,
-                       outOff, out);
+    const int blocks = (n + kGatherBlock - 1) / kGatherBlock;
+    hipLaunchKernelGGL(ops_block_sums_kernel, dim3(blocks), dim3(kGatherBlock), 0, stream, n, lens, blockSums);
+    hipLaunchKernelGGL(gather_ops_kernel, dim3(blocks), dim3(kGatherBlock), 0, stream, n, slots, slotBytes, lens,
+                       blockSums, base, next, out);
     return hipGetLastError();
 }
 
-hipError_t launchReverseJobs(int n, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
-                             int rules, PairJob* jobs, hipStream_t stream) {
+hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT,
+                             const int64_t* offsets, int rules, PairJob* jobs, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(reverse_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, endQ, endT, offsets,
-                       rules, jobs);
+    hipLaunchKernelGGL(reverse_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, score, endQ, endT,
+                       offsets, rules, jobs);
     return hipGetLastError();
 }
 
