@@ -98,3 +98,36 @@ def test_cfg4_mode_ordering_and_sample(capi):
         ref = _oracle.search(q, sres, soff, B62, 3, 1, "score", algo)["score"]
         np.testing.assert_array_equal(scores[algo][sample], ref)
     db.close()
+
+
+def test_cfg5_whole_database_on_one_gpu(capi):
+    # configs[4] unsharded: 53-aa query vs 10M x 400 (4e9 residues: offsets beyond 2^31), SW score.
+    # Every score against the AVX2 CPU baseline on the two ends and the middle of the database
+    # (the part of it where 32-bit residue offsets would wrap), the checker on a sample, and
+    # slice consistency across the 2^31 boundary.
+    n, length = 10_000_000, 400
+    rng = np.random.default_rng(3)
+    res = _data.AA20_CODES[rng.integers(0, 20, size=n * length, dtype=np.uint8)]
+    off = np.arange(n + 1, dtype=np.int64) * length
+    q = _oracle.encode(_data.README_QUERY)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        gpu = db.search(q, B62, 3, 1, "score", "sw")["score"]
+        assert gpu.shape == (n,)
+        for lo in (0, 5_368_000, n - 200_000):      # 5_368_709 * 400 = 2^31
+            hi = lo + 200_000
+            cpu = _cpu_baseline.CpuDatabase(res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
+            want = cpu.search_sw(q, B62, 3, 1, 16)
+            cpu.close()
+            np.testing.assert_array_equal(gpu[lo:hi], want, err_msg=f"targets {lo}..{hi}")
+        for lo in (0, 5_368_700, n - 500):
+            hi = lo + 500
+            ref = _oracle.search(q, res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo], B62, 3, 1, "end", "sw")
+            np.testing.assert_array_equal(gpu[lo:hi], ref["score"])
+            part = db.search(q, B62, 3, 1, "end", "sw", lo, hi)
+            for key in ("score", "end_q", "end_t"):
+                np.testing.assert_array_equal(part[key], ref[key], err_msg=f"{key} {lo}..{hi}")
+        part = db.search(q, B62, 3, 1, "score", "sw", 5_000_000, 6_000_000)["score"]
+        np.testing.assert_array_equal(part, gpu[5_000_000:6_000_000])
+    finally:
+        db.close()
