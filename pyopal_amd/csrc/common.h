@@ -88,7 +88,35 @@ struct WalkArgs {
     const int64_t* opsOff;    // [nJobs + 1], or null: job k owns the fixed slot k * opsSlot
     int64_t opsSlot;
     int32_t* opsLen;
+    // direction layout: 0 = intraseq_kernel (anti-diagonal major, at job.dirOff),
+    // > 0 = perpair_kernel ([j][i][lane] per 64 consecutive jobs, this many bytes apart)
+    int64_t dirWaveStride;
+    int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
+    // optional: score of the emitted alignment, recomputed from the operations (by job.out)
+    int32_t* walkScore;
+    const int* matrix;
+    int alphabet;
+    int gapOpen, gapExt;
 };
+
+// perpair_kernel: one lane per (query window, target window) pair of a one-strip query
+constexpr int kPerPairTrace = 4;  // beside the Region values: write direction bytes
+struct PerPairArgs {
+    const PairJob* jobs;      // borders penalised on both sides, no floor (rules bits 0..2 ignored)
+    int nJobs;
+    const uint8_t* residues;
+    const uint8_t* query;
+    int queryLength;          // <= 64
+    const int* matrix;
+    int alphabet;
+    int gapOpen, gapExt;
+    int32_t* score;           // by job.out (scan modes)
+    int32_t* endI;
+    int32_t* endJ;
+    uint8_t* dirs;            // trace: [job / 64][j][i][job % 64]
+    int64_t dirWaveStride;    // bytes per 64 consecutive jobs (>= longest target window * 4096)
+};
+hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 
 struct PackArgs {
     const uint8_t* residues;

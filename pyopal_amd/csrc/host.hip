@@ -1025,7 +1025,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     // (start cells, traceback jobs, direction bytes and operations are produced and
     // consumed on the device; the host only prefix-sums the alignment lengths)
     {
-        const int64_t slotDir = (db->maxLen + kLanes - 1) * kLanes;  // direction bytes of one pair
+        // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
+        const int64_t slotDir = (db->maxLen + kLanes - 1) * kLanes;
         const int64_t slotOps = queryLength + db->maxLen;            // operations of one pair
         const bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
                                 n * slotOps <= (8ll << 30) && !getenv("MIOPAL_HOST_TRACEBACK");
@@ -1040,6 +1041,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 outOff = localOff.data();
             }
             void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *pcompact, *pts;
+            // one lane per pair (perpair.hip) instead of one wavefront per pair (intraseq.hip)
+            const bool lanePerPair = !getenv("MIOPAL_NO_PERPAIR");
+            RC_TRY(s.ensurePairInputs());
+            PerPairArgs perPair{};
+            perPair.residues = db->d_residues;
+            perPair.query = s.d_query;
+            perPair.queryLength = queryLength;
+            perPair.matrix = s.d_matrix;
+            perPair.alphabet = alphabetLength;
+            perPair.gapOpen = gapOpen;
+            perPair.gapExt = gapExt;
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             RC_TRY(ws->get(kStartQ, (size_t)n * sizeof(int32_t), &psq));
             RC_TRY(ws->get(kStartT, (size_t)n * sizeof(int32_t), &pst));
@@ -1055,14 +1067,26 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
                                           db->d_offsets + start,
                                           packRules(rr), (PairJob*)pjobs, stream));
-                RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
+                if (lanePerPair) {
+                    PerPairArgs pa = perPair;
+                    pa.jobs = (const PairJob*)pjobs;
+                    pa.nJobs = (int)n;
+                    pa.score = (int32_t*)rs;
+                    pa.endI = (int32_t*)ri;
+                    pa.endJ = (int32_t*)rj;
+                    HIP_TRY(launchPerPair(pa, fr.region, stream));
+                } else {
+                    RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
+                }
             }
             HIP_TRY(launchStartCells((int)n, mode, gapOpen, gapExt, (const int32_t*)ps, (const int32_t*)pi,
                                      (const int32_t*)pj, (const int32_t*)rs, (const int32_t*)ri, (const int32_t*)rj,
                                      (int32_t*)psq, (int32_t*)pst, (int*)pmis, stream));
             pt.mark("start cells (enqueued)");
             // traceback in batches of whole direction slots
-            const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(n, kDirBudget * 4 / slotDir));
+            // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
+            const int64_t batch =
+                std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
             void *pd, *pslots;
             RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
             RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
@@ -1079,8 +1103,24 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                                         (const int32_t*)pst + b0, (const int32_t*)pi + b0, (const int32_t*)pj + b0,
                                         db->d_offsets + start + b0, slotDir, jobs, stream));
                 // job.out is relative to the batch: offset the score pointer
-                RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
                 WalkArgs wa{};
+                if (lanePerPair) {
+                    PerPairArgs pa = perPair;
+                    pa.jobs = jobs;
+                    pa.nJobs = nb;
+                    pa.dirs = (uint8_t*)pd;
+                    pa.dirWaveStride = slotDir * kLanes;
+                    HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
+                    wa.dirWaveStride = pa.dirWaveStride;
+                    // the score is added up again from the emitted operations
+                    wa.walkScore = (int32_t*)pts + b0;
+                    wa.matrix = s.d_matrix;
+                    wa.alphabet = alphabetLength;
+                    wa.gapOpen = gapOpen;
+                    wa.gapExt = gapExt;
+                } else {
+                    RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
+                }
                 wa.jobs = jobs;
                 wa.nJobs = nb;
                 wa.residues = db->d_residues;

@@ -198,28 +198,44 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     }
 }
 
-// One thread per pair: walk the direction bytes back from the end cell.
+// One thread per pair: walk the direction bytes back from the end cell. Optionally the score
+// of the emitted operations is added up again (substitutions, gap opens and extensions,
+// border gaps): the host compares it with the score of the search.
 __global__ void walk_kernel(WalkArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.nJobs) return;
     const PairJob job = a.jobs[idx];
     const int n = job.qLen, m = job.tLen;
     const int nSteps = m + kLanes - 1;
-    const uint8_t* dirs = a.dirs + job.dirOff;
+    const bool laneMajor = a.dirWaveStride > 0;
+    const uint8_t* dirs = laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
+                                    : a.dirs + job.dirOff;
     const uint8_t* q = a.query + job.qOff;
     const uint8_t* t = a.residues + job.tOff;
-    uint8_t* ops = a.opsOff ? a.ops + a.opsOff[idx] : a.ops + (int64_t)idx * a.opsSlot;
-    int64_t pos = a.opsOff ? a.opsOff[idx + 1] - a.opsOff[idx] : a.opsSlot;
-    int i = n - 1, j = m - 1, state = 0, len = 0;
+    const int slot = a.slotByOut ? job.out : idx;
+    uint8_t* ops = a.opsOff ? a.ops + a.opsOff[slot] : a.ops + (int64_t)slot * a.opsSlot;
+    int64_t pos = a.opsOff ? a.opsOff[slot + 1] - a.opsOff[slot] : a.opsSlot;
+    const bool rescore = a.walkScore != nullptr;
+    int i = n - 1, j = m - 1, state = 0, len = 0, total = 0;
     while (i >= 0 || j >= 0) {
-        if (i < 0) { ops[--pos] = 2; --j; ++len; continue; }
-        if (j < 0) { ops[--pos] = 1; --i; ++len; continue; }
+        if (i < 0) {
+            if (rescore) total += borderGap(j, a.gapOpen, a.gapExt);
+            for (; j >= 0; --j, ++len) ops[--pos] = 2;
+            break;
+        }
+        if (j < 0) {
+            if (rescore) total += borderGap(i, a.gapOpen, a.gapExt);
+            for (; i >= 0; --i, ++len) ops[--pos] = 1;
+            break;
+        }
         const int l = i & 63;
-        const uint8_t d = dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
+        const uint8_t d = laneMajor ? dirs[((int64_t)j * kLanes + i) * kLanes]
+                                    : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
         if (state == 0) {
             const int c = d & 3;
             if (c == 0) {
                 ops[--pos] = (q[i] == t[j]) ? 0 : 3;
+                if (rescore) total += a.matrix[q[i] * a.alphabet + t[j]];
                 ++len; --i; --j;
             } else {
                 state = c;
@@ -228,15 +244,18 @@ __global__ void walk_kernel(WalkArgs a) {
             ops[--pos] = 2;
             ++len;
             if (d & 4) state = 0;
+            if (rescore) total -= (d & 4) ? a.gapOpen : a.gapExt;
             --j;
         } else {
             ops[--pos] = 1;
             ++len;
             if (d & 8) state = 0;
+            if (rescore) total -= (d & 8) ? a.gapOpen : a.gapExt;
             --i;
         }
     }
-    a.opsLen[idx] = len;
+    a.opsLen[slot] = len;
+    if (rescore) a.walkScore[job.out] = total;
 }
 
 // Jobs of the start-location pass, built where the end locations already are (HBM):

@@ -1,0 +1,174 @@
+// Lane-per-pair kernel for gfx950: the second and third pass of a `full` search
+// (src/pyopal/opal.pxd:17-19, OPAL_SEARCH_ALIGNMENT) for queries of one 64-row strip.
+//
+// After the score/end pass every target has its own small problem anchored on its end cell:
+// the reversed prefixes q[endQ..0] x t[endT..0] (start-location scan) and then the rectangle
+// [start..end] (traceback directions). These problems share neither a query window nor a
+// length, so the wavefront-per-pair anti-diagonal kernel (intraseq.hip) spends most of its
+// steps filling and draining 64 lanes for ~50 columns. Here one LANE owns one pair and sweeps
+// it column by column at 32 bit, like the inter-sequence kernel but with a private query
+// window: H[64] / E[64] of the previous column live in VGPRs, the lane's query residues are
+// pre-scaled LDS row offsets packed two per VGPR, the substitution matrix sits in LDS with an
+// extra pad row and column. A wavefront runs until its longest pair is done.
+//
+// Rows beyond the lane's query window and columns beyond its target read the pad row/column
+// (a large negative score): every value computed there is bounded by a valid cell that comes
+// earlier in the column-major scan, so the strictly-greater candidate rule needs no masks
+// (region "all cells"); the other regions test the row/column explicitly.
+//
+// Model and tie-breaks: oracle/opal_oracle.c (rules 5-7).
+#include "common.h"
+
+namespace miopal {
+
+namespace {
+
+constexpr int kNegInf = INT32_MIN / 4;
+constexpr int kPadScore = -(1 << 28);
+constexpr int kStride = kMaxAlphabet + 1;  // matrix rows in LDS, in ints (pad column included)
+constexpr int kBlock = 256;
+
+template <int MODE>  // kAllCells / kLastRow / kLastRowCol: start-location scan; kPerPairTrace: directions
+__global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
+    __shared__ int smat[kStride * kStride];
+    __shared__ uint8_t qlds[kLanes];
+    const int A = a.alphabet;
+    for (int idx = threadIdx.x; idx < kStride * kStride; idx += kBlock) {
+        const int q = idx / kStride, t = idx % kStride;
+        // `open` is folded into the scores: the columns keep H - open (see the cell update)
+        smat[idx] = (q < A && t < A) ? a.matrix[q * A + t] + a.gapOpen : kPadScore;
+    }
+    if (threadIdx.x < kLanes) qlds[threadIdx.x] = threadIdx.x < a.queryLength ? a.query[threadIdx.x] : 0;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < a.nJobs;
+    PairJob job{};
+    if (active) job = a.jobs[idx];
+    const int Q = job.qLen, L = job.tLen;
+    const int open = a.gapOpen, ext = a.gapExt;
+
+    int maxQ = Q, maxL = L;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        maxQ = max(maxQ, __shfl_xor(maxQ, off));
+        maxL = max(maxL, __shfl_xor(maxL, off));
+    }
+    maxQ = __builtin_amdgcn_readfirstlane(maxQ);
+    maxL = __builtin_amdgcn_readfirstlane(maxL);
+
+    // LDS byte offsets of the lane's query rows, two per register; pad row beyond the window
+    uint32_t qo[kLanes / 2];
+#pragma unroll
+    for (int i = 0; i < kLanes; i += 2) {
+        const int q0 = i < Q ? qlds[job.qOff + i * job.qStep] : A;
+        const int q1 = i + 1 < Q ? qlds[job.qOff + (i + 1) * job.qStep] : A;
+        qo[i >> 1] = (uint32_t)(q0 * kStride * 4) | ((uint32_t)(q1 * kStride * 4) << 16);
+    }
+
+    // Previous column, kept as HM = H - open: the same number opens a gap to the right (E of
+    // the next column) and downwards (F of the next row), and the diagonal gets `open` back
+    // from the LDS scores.
+    int HM[kLanes], E[kLanes];
+#pragma unroll
+    for (int i = 0; i < kLanes; ++i) {
+        HM[i] = i < Q ? borderGap(i, open, ext) - open : kNegInf;  // column -1
+        E[i] = kNegInf;
+    }
+
+    int best = INT32_MIN, brow = -1, bcol = -1;
+    const bool stopOn = job.rules & kRuleStop;
+    const int stopScore = job.stop;
+    const uint8_t* tptr = a.residues + job.tOff;
+    const int64_t tStep = job.tStep;
+    uint8_t* dcol = nullptr;
+    if (MODE == kPerPairTrace) dcol = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane;
+
+    int tcolNext = (L > 0 ? (int)tptr[0] : A) * 4;
+    for (int j = 0; j < maxL; ++j) {
+        const int tcol = tcolNext;
+        {
+            int t = A;
+            if (j + 1 < L) t = tptr[(int64_t)(j + 1) * tStep];
+            tcolNext = t * 4;
+        }
+        const char* mcol = (const char*)smat + tcol;
+        int hmUp = borderGap(j, open, ext) - open, fUp = kNegInf;
+        int hmDiag = (j == 0 ? 0 : borderGap(j - 1, open, ext)) - open;
+        const bool colOk = j < L, lastCol = j == L - 1;
+        const int bestBefore = best;
+#pragma unroll
+        for (int i = 0; i < kLanes; ++i) {
+            if ((i & 7) == 0 && i >= maxQ) break;  // wave-uniform
+            const uint32_t off = (i & 1) ? (qo[i >> 1] >> 16) : (qo[i >> 1] & 0xffffu);
+            const int sc = *(const int*)(mcol + off);
+            const int eOpen = HM[i], eExt = E[i] - ext;
+            const int fOpen = hmUp, fExt = fUp - ext;
+            const int e = max(eOpen, eExt);
+            const int f = max(fOpen, fExt);
+            const int d = hmDiag + sc;
+            const int h = max(d, max(e, f));
+            if (MODE == kPerPairTrace) {
+                // same code as intraseq_kernel<true>: diag > E (target gap) > F (query gap);
+                // inside a gap, closing it is preferred to extending it
+                const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
+                const int code = which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0);
+                dcol[((int64_t)j * kLanes + i) * kLanes] = (uint8_t)code;
+            } else {
+                bool cand = true;  // kAllCells: pad rows / columns never beat a valid cell
+                if (MODE == kLastRow) cand = colOk && i == Q - 1;
+                if (MODE == kLastRowCol) cand = colOk && (i == Q - 1 || (lastCol && i < Q));
+                const bool take = cand && h > best;
+                best = take ? h : best;
+                brow = take ? i : brow;
+            }
+            const int hm = h - open;
+            hmDiag = HM[i];
+            HM[i] = hm;
+            E[i] = e;
+            hmUp = hm;
+            fUp = f;
+        }
+        if (MODE != kPerPairTrace) {
+            bcol = best != bestBefore ? j : bcol;  // candidates only ever raise `best`
+            // the optimum of the forward pass is the first maximum of this scan: a lane that
+            // met it is finished; the wavefront leaves when no lane has work left
+            const bool more = j + 1 < L && !(stopOn && best == stopScore);
+            if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+        }
+    }
+
+    if (MODE != kPerPairTrace && active) {
+        int bi = -1, bj = -1;
+        if (Q > 0 && L > 0) {
+            bi = brow;
+            bj = bcol;
+        } else {
+            // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+            best = 0;
+            if (Q > 0) best = borderGap(Q - 1, open, ext);
+            if (L > 0) best = borderGap(L - 1, open, ext);
+        }
+        a.score[job.out] = best;
+        if (a.endI) a.endI[job.out] = bi;
+        if (a.endJ) a.endJ[job.out] = bj;
+    }
+}
+
+}  // namespace
+
+hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    const dim3 grid((a.nJobs + kBlock - 1) / kBlock), block(kBlock);
+    switch (mode) {
+        case kAllCells: hipLaunchKernelGGL((perpair_kernel<kAllCells>), grid, block, 0, stream, a); break;
+        case kLastRow: hipLaunchKernelGGL((perpair_kernel<kLastRow>), grid, block, 0, stream, a); break;
+        case kLastRowCol: hipLaunchKernelGGL((perpair_kernel<kLastRowCol>), grid, block, 0, stream, a); break;
+        case kPerPairTrace: hipLaunchKernelGGL((perpair_kernel<kPerPairTrace>), grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace miopal
