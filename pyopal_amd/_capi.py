@@ -222,15 +222,16 @@ class DeviceDatabase:
         q = np.ascontiguousarray(query, dtype=np.uint8)
         S = np.ascontiguousarray(matrix, dtype=np.int32)
         st = SEARCH[mode]
-        out = {"score": np.zeros(n, dtype=np.int32)}
+        # the C side writes every entry of its outputs (locations of empty alignments are -1)
+        out = {"score": np.empty(n, dtype=np.int32)}
         et = eq = s_t = s_q = aoff = None
         ops_ptr = ctypes.c_void_p()
         if st >= 1:
-            et = np.full(n, -1, dtype=np.int32)
-            eq = np.full(n, -1, dtype=np.int32)
+            et = np.empty(n, dtype=np.int32)
+            eq = np.empty(n, dtype=np.int32)
         if st == 2:
-            s_t = np.full(n, -1, dtype=np.int32)
-            s_q = np.full(n, -1, dtype=np.int32)
+            s_t = np.empty(n, dtype=np.int32)
+            s_q = np.empty(n, dtype=np.int32)
             aoff = np.zeros(n + 1, dtype=np.int64)
         rc = lib().miopalSearchFlat(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
                                     self.alphabet_length, st, MODE[algorithm], start, end,

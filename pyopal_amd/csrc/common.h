@@ -165,6 +165,9 @@ hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* s
 hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
                            const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
                            hipStream_t stream);
+// Counting sort by tLen, longest first (maxLen <= kLongTarget: the bins fit LDS). bins: maxLen + 1 ints.
+hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
+                                  hipStream_t stream);
 // blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
                            int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,

@@ -135,7 +135,7 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kSlots
 };
 
 struct Workspace {
@@ -1087,7 +1087,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
             const int64_t batch =
                 std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
-            void *pd, *pslots;
+            void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
+            const bool sortJobs = lanePerPair && db->maxLen <= kLongTarget;  // bins live in LDS
+            if (sortJobs) {
+                RC_TRY(ws->get(kSortBins, (size_t)(db->maxLen + 1) * sizeof(int), &pbins));
+                RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
+            }
             RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
             RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
             RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
@@ -1105,6 +1110,13 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 // job.out is relative to the batch: offset the score pointer
                 WalkArgs wa{};
                 if (lanePerPair) {
+                    // neighbours of similar length share a wavefront; results stay addressed by job.out
+                    if (sortJobs) {
+                        HIP_TRY(launchSortJobsByLength(jobs, nb, (int)db->maxLen, (int*)pbins, (PairJob*)psorted,
+                                                       stream));
+                        jobs = (PairJob*)psorted;
+                        wa.slotByOut = 1;
+                    }
                     PerPairArgs pa = perPair;
                     pa.jobs = jobs;
                     pa.nJobs = nb;

@@ -10,6 +10,8 @@
 // carries targets too long for one-lane-per-target scheduling.
 //
 // Model and tie-breaks: oracle/opal_oracle.c.
+#include <algorithm>
+
 #include "common.h"
 
 namespace miopal {
@@ -393,6 +395,85 @@ __global__ __launch_bounds__(kGatherBlock) void gather_ops_kernel(int n, const u
     const uint8_t* src = slots + (int64_t)(k + 1) * slotBytes - len;
     uint8_t* dst = out + dstOff;
     for (int i = 0; i < len; ++i) dst[i] = src[i];
+}
+
+// ---- counting sort of pair jobs by target-window length, longest first ---------------
+// perpair_kernel runs a wavefront until its longest pair is done: 64 neighbours of similar
+// length waste few columns, and the longest wavefronts start first.
+constexpr int kSortBlock = 1024;
+
+__global__ __launch_bounds__(kSortBlock) void job_length_histogram_kernel(const PairJob* jobs, int n, int maxLen,
+                                                                          int* bins) {
+    extern __shared__ int local[];
+    for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
+    __syncthreads();
+    for (int k = blockIdx.x * kSortBlock + threadIdx.x; k < n; k += gridDim.x * kSortBlock)
+        atomicAdd(&local[min(jobs[k].tLen, maxLen)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b <= maxLen; b += kSortBlock)
+        if (local[b]) atomicAdd(&bins[b], local[b]);
+}
+
+// bins[b] <- first position of length b in the sorted order (lengths descending); one block
+__global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxLen, int* bins) {
+    __shared__ int partial[kSortBlock];
+    const int nBins = maxLen + 1;
+    const int per = (nBins + kSortBlock - 1) / kSortBlock;
+    // thread t owns the bins of rank [t * per, (t + 1) * per) counted from the longest
+    int sum = 0;
+    for (int r = threadIdx.x * per; r < min(nBins, (threadIdx.x + 1) * per); ++r) sum += bins[maxLen - r];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < kSortBlock; off <<= 1) {
+        const int v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        __syncthreads();
+        partial[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = partial[threadIdx.x] - sum;
+    for (int r = threadIdx.x * per; r < min(nBins, (threadIdx.x + 1) * per); ++r) {
+        const int c = bins[maxLen - r];
+        bins[maxLen - r] = run;
+        run += c;
+    }
+}
+
+// Scatter: a block ranks its jobs per length in LDS and reserves one range per (block, length)
+// with a single global atomic, instead of one contended atomic per job.
+__global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const PairJob* jobs, int n, int maxLen,
+                                                                        int* bins, PairJob* sorted) {
+    extern __shared__ int local[];
+    for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
+    __syncthreads();
+    const int k = blockIdx.x * kSortBlock + threadIdx.x;
+    PairJob j{};
+    int key = 0, rank = 0;
+    if (k < n) {
+        j = jobs[k];
+        key = min(j.tLen, maxLen);
+        rank = atomicAdd(&local[key], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) {
+        const int c = local[b];
+        if (c) local[b] = atomicAdd(&bins[b], c);
+    }
+    __syncthreads();
+    if (k < n) sorted[local[key] + rank] = j;
+}
+
+hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
+                                  hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(bins, 0, (size_t)(maxLen + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int blocks = std::min((n + kSortBlock - 1) / kSortBlock, 1024);
+    hipLaunchKernelGGL(job_length_histogram_kernel, dim3(blocks), dim3(kSortBlock),
+                       (size_t)(maxLen + 1) * sizeof(int), stream, jobs, n, maxLen, bins);
+    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxLen, bins);
+    hipLaunchKernelGGL(job_length_scatter_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
+                       (size_t)(maxLen + 1) * sizeof(int), stream, jobs, n, maxLen, bins, sorted);
+    return hipGetLastError();
 }
 
 hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* score, const int32_t* endQ,
