@@ -92,11 +92,7 @@ struct WalkArgs {
     // > 0 = perpair_kernel ([j][i][lane] per 64 consecutive jobs, this many bytes apart)
     int64_t dirWaveStride;
     int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
-    // optional: score of the emitted alignment, recomputed from the operations (by job.out)
-    int32_t* walkScore;
-    const int* matrix;
-    int alphabet;
-    int gapOpen, gapExt;
+    int queryLength;          // whole query (staged in LDS when it fits)
 };
 
 // perpair_kernel: one lane per (query window, target window) pair of a one-strip query
@@ -110,7 +106,7 @@ struct PerPairArgs {
     const int* matrix;
     int alphabet;
     int gapOpen, gapExt;
-    int32_t* score;           // by job.out (scan modes)
+    int32_t* score;           // by job.out (trace: score of the last cell of the window)
     int32_t* endI;
     int32_t* endJ;
     uint8_t* dirs;            // trace: [job / 64][j][i][job % 64]

@@ -1027,7 +1027,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     {
         // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
         const int64_t slotDir = (db->maxLen + kLanes - 1) * kLanes;
-        const int64_t slotOps = queryLength + db->maxLen;            // operations of one pair
+        const int64_t slotOps = (queryLength + db->maxLen + 3) & ~(int64_t)3;  // operations of one pair
         const bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
                                 n * slotOps <= (8ll << 30) && !getenv("MIOPAL_HOST_TRACEBACK");
         if (deviceFull) {
@@ -1121,15 +1121,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     pa.jobs = jobs;
                     pa.nJobs = nb;
                     pa.dirs = (uint8_t*)pd;
+                    pa.score = (int32_t*)pts + b0;  // job.out is relative to the batch
                     pa.dirWaveStride = slotDir * kLanes;
                     HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
                     wa.dirWaveStride = pa.dirWaveStride;
-                    // the score is added up again from the emitted operations
-                    wa.walkScore = (int32_t*)pts + b0;
-                    wa.matrix = s.d_matrix;
-                    wa.alphabet = alphabetLength;
-                    wa.gapOpen = gapOpen;
-                    wa.gapExt = gapExt;
                 } else {
                     RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
                 }
@@ -1141,6 +1136,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 wa.ops = (uint8_t*)pslots;
                 wa.opsOff = nullptr;
                 wa.opsSlot = slotOps;
+                wa.queryLength = queryLength;
                 wa.opsLen = (int32_t*)plen + b0;
                 HIP_TRY(launchWalk(wa, stream));
                 HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
@@ -1322,6 +1318,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         wa.ops = (uint8_t*)po;
         wa.opsOff = (const int64_t*)poff;
         wa.opsLen = (int32_t*)plen;
+        wa.queryLength = queryLength;
         HIP_TRY(launchWalk(wa, stream));
         if (pt.on) { HIP_TRY(hipStreamSynchronize(stream)); pt.mark("  trace + walk kernels"); }
         const size_t opsBytes = (size_t)opsOff.back();

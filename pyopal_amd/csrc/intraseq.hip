@@ -200,10 +200,18 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     }
 }
 
-// One thread per pair: walk the direction bytes back from the end cell. Optionally the score
-// of the emitted operations is added up again (substitutions, gap opens and extensions,
-// border gaps): the host compares it with the score of the search.
-__global__ void walk_kernel(WalkArgs a) {
+// One thread per pair: walk the direction bytes back from the end cell. Every memory access of
+// a step is divergent (64 lanes, 64 lines), so the step is kept to ONE such access, the
+// direction byte: the query sits in LDS, the target residues are fetched four at a time, and
+// with fixed slots the operations leave as whole dwords.
+constexpr int kWalkQueryLds = 4096;
+
+__global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
+    __shared__ uint8_t qlds[kWalkQueryLds];
+    const bool queryInLds = a.queryLength <= kWalkQueryLds;
+    if (queryInLds)
+        for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];
+    __syncthreads();
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.nJobs) return;
     const PairJob job = a.jobs[idx];
@@ -213,21 +221,31 @@ __global__ void walk_kernel(WalkArgs a) {
     const uint8_t* dirs = laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
                                     : a.dirs + job.dirOff;
     const uint8_t* q = a.query + job.qOff;
-    const uint8_t* t = a.residues + job.tOff;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
     const int slot = a.slotByOut ? job.out : idx;
     uint8_t* ops = a.opsOff ? a.ops + a.opsOff[slot] : a.ops + (int64_t)slot * a.opsSlot;
     int64_t pos = a.opsOff ? a.opsOff[slot + 1] - a.opsOff[slot] : a.opsSlot;
-    const bool rescore = a.walkScore != nullptr;
-    int i = n - 1, j = m - 1, state = 0, len = 0, total = 0;
+    const bool dwords = !a.opsOff && (a.opsSlot & 3) == 0;  // slots start and end on dword boundaries
+    uint32_t acc = 0, tword = 0;
+    int64_t twordAt = -1;
+    int i = n - 1, j = m - 1, state = 0, len = 0;
+    auto emit = [&](uint32_t op) {
+        ++len;
+        --pos;
+        if (dwords) {
+            acc = (acc << 8) | op;  // the newest operation has the lowest address
+            if ((pos & 3) == 0) *reinterpret_cast<uint32_t*>(ops + pos) = acc;
+        } else {
+            ops[pos] = (uint8_t)op;
+        }
+    };
     while (i >= 0 || j >= 0) {
         if (i < 0) {
-            if (rescore) total += borderGap(j, a.gapOpen, a.gapExt);
-            for (; j >= 0; --j, ++len) ops[--pos] = 2;
+            for (; j >= 0; --j) emit(2);
             break;
         }
         if (j < 0) {
-            if (rescore) total += borderGap(i, a.gapOpen, a.gapExt);
-            for (; i >= 0; --i, ++len) ops[--pos] = 1;
+            for (; i >= 0; --i) emit(1);
             break;
         }
         const int l = i & 63;
@@ -236,28 +254,34 @@ __global__ void walk_kernel(WalkArgs a) {
         if (state == 0) {
             const int c = d & 3;
             if (c == 0) {
-                ops[--pos] = (q[i] == t[j]) ? 0 : 3;
-                if (rescore) total += a.matrix[q[i] * a.alphabet + t[j]];
-                ++len; --i; --j;
+                const int64_t at = job.tOff + j;  // forward jobs only (tStep = 1)
+                if ((at >> 2) != twordAt) {
+                    twordAt = at >> 2;
+                    tword = words[twordAt];
+                }
+                const uint32_t tr = (tword >> ((at & 3) * 8)) & 0xffu;
+                const uint32_t qr = queryInLds ? qlds[job.qOff + i] : q[i];
+                emit(qr == tr ? 0 : 3);
+                --i; --j;
             } else {
                 state = c;
             }
         } else if (state == 1) {
-            ops[--pos] = 2;
-            ++len;
+            emit(2);
             if (d & 4) state = 0;
-            if (rescore) total -= (d & 4) ? a.gapOpen : a.gapExt;
             --j;
         } else {
-            ops[--pos] = 1;
-            ++len;
+            emit(1);
             if (d & 8) state = 0;
-            if (rescore) total -= (d & 8) ? a.gapOpen : a.gapExt;
             --i;
         }
     }
+    if (dwords && (pos & 3)) {
+        // the lowest dword is only partly filled: its top bytes go out one by one
+        const int fill = 4 - (int)(pos & 3);
+        for (int x = 0; x < fill; ++x) ops[pos + x] = (uint8_t)(acc >> (8 * x));
+    }
     a.opsLen[slot] = len;
-    if (rescore) a.walkScore[job.out] = total;
 }
 
 // Jobs of the start-location pass, built where the end locations already are (HBM):
@@ -389,12 +413,20 @@ __global__ __launch_bounds__(kGatherBlock) void gather_ops_kernel(int n, const u
         scan[t] += v;
         __syncthreads();
     }
-    if (k >= n) return;
+    // the wavefront copies its 64 alignments one after the other, 64 bytes per step: both
+    // sides of the copy are contiguous runs
     const int64_t dstOff = *base + red[0] + scan[t] - len;
     if (k == n - 1) *next = dstOff + len;
-    const uint8_t* src = slots + (int64_t)(k + 1) * slotBytes - len;
-    uint8_t* dst = out + dstOff;
-    for (int i = 0; i < len; ++i) dst[i] = src[i];
+    const int64_t srcOff = (int64_t)(k + 1) * slotBytes - len;
+    const int lane = t & 63;
+#pragma unroll 1
+    for (int p = 0; p < 64; ++p) {
+        const int plen = __shfl(len, p);
+        if (plen == 0) continue;  // wave-uniform
+        const uint8_t* src = slots + __shfl(srcOff, p);
+        uint8_t* dst = out + __shfl(dstOff, p);
+        for (int i = lane; i < plen; i += 64) dst[i] = src[i];
+    }
 }
 
 // ---- counting sort of pair jobs by target-window length, longest first ---------------

@@ -130,7 +130,16 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
             hmUp = hm;
             fUp = f;
         }
-        if (MODE != kPerPairTrace) {
+        if (MODE == kPerPairTrace) {
+            // score of the window = its last cell; lanes of a wavefront (sorted by length)
+            // finish in a handful of columns, so the row select runs rarely
+            if (__builtin_amdgcn_ballot_w64(lastCol) != 0) {
+                int v = 0;
+#pragma unroll
+                for (int i = 0; i < kLanes; ++i) v = (i == Q - 1) ? HM[i] : v;
+                if (lastCol) best = v + open;
+            }
+        } else {
             bcol = best != bestBefore ? j : bcol;  // candidates only ever raise `best`
             // the optimum of the forward pass is the first maximum of this scan: a lane that
             // met it is finished; the wavefront leaves when no lane has work left
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
         }
     }
 
-    if (MODE != kPerPairTrace && active) {
+    if (active) {
         int bi = -1, bj = -1;
         if (Q > 0 && L > 0) {
             bi = brow;
@@ -151,8 +160,8 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
             if (L > 0) best = borderGap(L - 1, open, ext);
         }
         a.score[job.out] = best;
-        if (a.endI) a.endI[job.out] = bi;
-        if (a.endJ) a.endJ[job.out] = bj;
+        if (MODE != kPerPairTrace && a.endI) a.endI[job.out] = bi;
+        if (MODE != kPerPairTrace && a.endJ) a.endJ[job.out] = bj;
     }
 }
 
