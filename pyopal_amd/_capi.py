@@ -192,6 +192,7 @@ class DeviceDatabase:
         raise_for(rc)
         self._h = handle
         self.count = len(offsets) - 1
+        self.offsets = offsets            # host copy: target k is residues[offsets[k]:offsets[k + 1]]
         self.alphabet_length = alphabet_length
         self.device = device
 

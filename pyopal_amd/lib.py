@@ -582,8 +582,22 @@ class Aligner:
         """Extension: the scores of ``align(mode="score")`` as
         one ``int32`` array instead of a list of `ScoreResult` objects, which for a
         million targets costs more wall time than the search itself."""
+        return self.align_arrays(query, database, mode="score", algorithm=algorithm, start=start,
+                                 end=end, device=device).score
+
+    def align_arrays(self, query, database: BaseDatabase, *, mode: str = "score",
+                     algorithm: str = "sw", start: int = 0, end: int = UINT32_MAX,
+                     device: int = 0) -> "ResultArrays":
+        """Extension: the results of `align` as arrays, one entry
+        per target of ``database[start:end]``, without a Python object per target. The
+        returned `ResultArrays` builds the reference's result objects on demand
+        (``arrays[k]``, iteration), so ``list(arrays) == aligner.align(...)``."""
+        if mode not in _OPAL_SEARCH_MODES:
+            raise ValueError(f"invalid search mode: {mode!r}")
         if algorithm not in _OPAL_ALGORITHMS:
             raise ValueError(f"invalid algorithm: {algorithm!r}")
+        if start < 0 or end < 0:
+            raise OverflowError("can't convert negative value to uint32_t")
         if database.alphabet != self.alphabet:
             raise ValueError("database and score matrix have different alphabets")
         encoded = database.alphabet.encode(query)
@@ -595,13 +609,76 @@ class Aligner:
             if start > size:
                 raise IndexError("database slice start is past the end of the database")
             if end == start:
-                return np.zeros(0, dtype=np.int32)
+                out = {"score": np.zeros(0, dtype=np.int32)}
+                if mode != "score":
+                    out.update(end_q=np.zeros(0, dtype=np.int32), end_t=np.zeros(0, dtype=np.int32))
+                if mode == "full":
+                    out.update(start_q=np.zeros(0, dtype=np.int32), start_t=np.zeros(0, dtype=np.int32),
+                               aln_flat=np.zeros(0, dtype=np.uint8), aln_off=np.zeros(1, dtype=np.int64))
+                return ResultArrays(mode, start, len(encoded), [], out)
             if _capi.lib().miopalDeviceCount() < 1:
                 raise RuntimeError("no supported SIMD backend available")
             mirror = database._device_mirror(device)
             out = mirror.search(np.frombuffer(encoded, dtype=np.uint8), _int_matrix_array(self._int_matrix),
-                                self.gap_open, self.gap_extend, "score", algorithm, start, end)
-            return out["score"]
+                                self.gap_open, self.gap_extend, mode, algorithm, start, end)
+            lengths = np.diff(mirror.offsets[start:end + 1]) if mode == "full" else None
+            return ResultArrays(mode, start, len(encoded), lengths, out)
+
+
+class ResultArrays:
+    """Results of one search as arrays (`Aligner.align_arrays`).
+
+    Attributes (``int32`` arrays, one entry per target of the slice): ``score``; for the
+    ``end`` and ``full`` modes ``query_end``, ``target_end``; for ``full`` also
+    ``query_start``, ``target_start``, ``target_length`` and the alignments as one ``uint8``
+    buffer ``operations`` (codes of ``src/pyopal/opal.pxd:21-24``) with ``operation_offsets``
+    (``int64``, n + 1 entries). Indexing and iteration yield `ScoreResult` / `EndResult` /
+    `FullResult` objects equal to those of `Aligner.align`.
+    """
+
+    def __init__(self, mode: str, start: int, query_length: int, target_lengths, out):
+        self.mode = mode
+        self.start = start
+        self.query_length = query_length
+        self.score = out["score"]
+        self.query_end = out.get("end_q")
+        self.target_end = out.get("end_t")
+        self.query_start = out.get("start_q")
+        self.target_start = out.get("start_t")
+        self.operations = out.get("aln_flat")
+        self.operation_offsets = out.get("aln_off")
+        self.target_length = target_lengths if mode == "full" else None
+
+    def __len__(self) -> int:
+        return len(self.score)
+
+    def alignment(self, k: int) -> str:
+        """The operations of target ``k`` of the slice over ``MDIX`` (`FullResult.alignment`)."""
+        if self.mode != "full":
+            raise ValueError("alignments are only computed in 'full' mode")
+        lo, hi = self.operation_offsets[k], self.operation_offsets[k + 1]
+        return self.operations[lo:hi].tobytes().translate(_OPS_TO_TEXT).decode("ascii")
+
+    def __getitem__(self, k: int):
+        n = len(self)
+        if k < 0:
+            k += n
+        if k < 0 or k >= n:
+            raise IndexError(k)
+        index = self.start + k
+        if self.mode == "score":
+            return ScoreResult(index, int(self.score[k]))
+        if self.mode == "end":
+            return EndResult(index, int(self.score[k]), int(self.query_end[k]), int(self.target_end[k]))
+        return FullResult(index, int(self.score[k]), int(self.query_end[k]), int(self.target_end[k]),
+                          int(self.query_start[k]), int(self.target_start[k]), self.query_length,
+                          int(self.target_length[k]), self.alignment(k))
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+_OPS_TO_TEXT = bytes.maketrans(bytes([0, 1, 2, 3]), b"MDIX")  # src/pyopal/lib.pyx:991
 
 
 def _int_matrix_array(matrix) -> np.ndarray:

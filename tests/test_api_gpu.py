@@ -122,3 +122,26 @@ def test_concurrent_queries_share_one_database():
     m = np.array(aligner.scoring_matrix.int_array(), dtype=np.int32)
     ref = _oracle.search(_oracle.encode(queries[0]), res, off, m, 3, 1, "score", "sw")
     assert want[0] == ref["score"].tolist()
+
+
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_align_arrays_extension_matches_align(mode):
+    # array results, equal to the list of result objects
+    rng = np.random.default_rng(77)
+    seqs = ["".join(rng.choice(list(_data.AA20), size=int(n))) for n in rng.integers(1, 120, size=300)]
+    db = pyopal.Database(seqs)
+    aligner = pyopal.Aligner(gap_open=3, gap_extend=1)
+    for algo in ("nw", "hw", "ov", "sw"):
+        want = aligner.align(seqs[5], db, mode=mode, algorithm=algo, start=7, end=290)
+        got = aligner.align_arrays(seqs[5], db, mode=mode, algorithm=algo, start=7, end=290)
+        assert len(got) == len(want) == 283
+        assert got.score.tolist() == [r.score for r in want]
+        assert list(got) == want
+        assert got[-1] == want[-1]
+        if mode == "full":
+            assert got.alignment(3) == want[3].alignment
+            assert got.target_length.tolist() == [len(s) for s in seqs[7:290]]
+    empty = aligner.align_arrays(seqs[5], db, mode=mode, start=10, end=10)
+    assert len(empty) == 0 and list(empty) == []
+    with pytest.raises(ValueError):
+        aligner.align_arrays(seqs[5], db, mode="nope")
