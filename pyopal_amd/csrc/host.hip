@@ -93,7 +93,8 @@ struct HostBytes {
     bool reserve(size_t want) {
         if (want <= cap) return true;
         want = std::max(want, cap + cap / 2);
-        if (!data && want >= (8u << 20)) {
+        static const bool hugePages = !getenv("MIOPAL_NO_HUGEPAGE");
+        if (!data && want >= (8u << 20) && hugePages) {
             // a large result buffer is written once, front to back: ask for huge pages so that
             // first touch costs tens of faults instead of tens of thousands
             void* p = nullptr;
@@ -156,6 +157,7 @@ struct Workspace {
     size_t pinnedCap = 0, pinnedUsed = 0;
     struct Pending { void* dst; size_t off, bytes; };
     std::vector<Pending> pending;
+    std::vector<int32_t> hostScratchA, hostScratchB;  // per-target host arrays of a full search
 
     // Large results land in pages the caller has not touched yet; a few threads fault them in
     // side by side.
@@ -176,30 +178,51 @@ struct Workspace {
         for (auto& th : pool) th.join();
     }
 
+    // Every per-search transfer goes through this pinned buffer, in both directions. Copying
+    // from or to the caller's pageable memory makes the runtime pin those pages for the
+    // transfer; when the caller later frees or trims that memory (a result buffer, a heap
+    // that shrinks) the driver has to quiesce the process's queues to drop the mapping -
+    // measured as a 20-30 ms stall of the NEXT search.
     int finishDownloads() {
-        if (pending.empty()) return 0;
+        if (pending.empty() && pinnedUsed == 0) return 0;
         HIP_TRY(hipStreamSynchronize(stream));
+        if (aux) HIP_TRY(hipStreamSynchronize(aux));
         for (const Pending& p : pending) copyOut(p.dst, (const char*)pinned + p.off, p.bytes);
         pending.clear();
         pinnedUsed = 0;
         return 0;
     }
+    // room for `bytes` more in the staging buffer (drains it, and grows it, when needed)
+    int reserveStaging(size_t aligned) {
+        if (pinnedUsed + aligned <= pinnedCap) return 0;
+        RC_TRY(finishDownloads());
+        if (aligned > pinnedCap) {
+            if (pinned) HIP_TRY(hipHostFree(pinned));
+            pinned = nullptr;
+            pinnedCap = 0;
+            const size_t want = aligned + aligned / 4 + (1u << 20);
+            HIP_TRY(hipHostMalloc(&pinned, want, hipHostMallocDefault));
+            pinnedCap = want;
+        }
+        return 0;
+    }
     int stageDownload(void* dst, const void* deviceSrc, size_t bytes) {
         if (bytes == 0) return 0;
         const size_t aligned = (bytes + 255) & ~(size_t)255;
-        if (pinnedUsed + aligned > pinnedCap) {
-            RC_TRY(finishDownloads());
-            if (aligned > pinnedCap) {
-                if (pinned) HIP_TRY(hipHostFree(pinned));
-                pinned = nullptr;
-                pinnedCap = 0;
-                const size_t want = aligned + aligned / 4 + (1u << 20);
-                HIP_TRY(hipHostMalloc(&pinned, want, hipHostMallocDefault));
-                pinnedCap = want;
-            }
-        }
+        RC_TRY(reserveStaging(aligned));
         HIP_TRY(hipMemcpyAsync((char*)pinned + pinnedUsed, deviceSrc, bytes, hipMemcpyDeviceToHost, stream));
         pending.push_back({dst, pinnedUsed, bytes});
+        pinnedUsed += aligned;
+        return 0;
+    }
+    // host -> device on `on` (the workspace's stream or its side stream); `src` may be reused
+    // as soon as the call returns
+    int stageUpload(void* deviceDst, const void* src, size_t bytes, hipStream_t on) {
+        if (bytes == 0) return 0;
+        const size_t aligned = (bytes + 255) & ~(size_t)255;
+        RC_TRY(reserveStaging(aligned));
+        memcpy((char*)pinned + pinnedUsed, src, bytes);
+        HIP_TRY(hipMemcpyAsync(deviceDst, (const char*)pinned + pinnedUsed, bytes, hipMemcpyHostToDevice, on));
         pinnedUsed += aligned;
         return 0;
     }
@@ -358,19 +381,47 @@ struct WorkspaceLease {
     }
 };
 
-template <typename T>
-int upload(T* dst, const T* src, size_t n, hipStream_t s) {
-    if (n == 0) return 0;
-    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
-    // sources are short-lived host vectors: do not rely on the runtime having staged a
-    // large pageable buffer by the time the call returns
-    if (n * sizeof(T) > (1u << 16)) HIP_TRY(hipStreamSynchronize(s));
-    return 0;
-}
-template <typename T>
-int download(T* dst, const T* src, size_t n, hipStream_t s) {
-    if (n == 0) return 0;
-    HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s));
+// One-off host -> device copy (database and view construction) through a pinned bounce buffer,
+// so that the runtime never pins (and keeps a mapping of) the caller's or the C library's
+// pageable memory: see Workspace::finishDownloads.
+int uploadOnce(void* deviceDst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    const size_t piece = std::min<size_t>(bytes, 32u << 20);
+    void* bounce[2] = {nullptr, nullptr};
+    hipStream_t s = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (s) (void)hipStreamDestroy(s);
+        for (void* b : bounce)
+            if (b) (void)hipHostFree(b);
+    };
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(&bounce[0], piece, hipHostMallocDefault) != hipSuccess ||
+        (bytes > piece && hipHostMalloc(&bounce[1], piece, hipHostMallocDefault) != hipSuccess)) {
+        cleanup();
+        return fail(MIOPAL_ERR_HIP, "cannot allocate the upload bounce buffer");
+    }
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2 && rc == 0; ++k)
+        if (hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) rc = 1;
+    size_t off = 0;
+    for (int k = 0; off < bytes && rc == 0; ++k) {
+        const int b = k & 1;
+        const size_t nb = std::min(piece, bytes - off);
+        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) rc = 1;   // buffer b is free again
+        if (rc == 0) {
+            memcpy(bounce[b], (const char*)src + off, nb);
+            if (hipMemcpyAsync((char*)deviceDst + off, bounce[b], nb, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipEventRecord(done[b], s) != hipSuccess)
+                rc = 1;
+        }
+        off += nb;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
+    for (hipEvent_t e : done)
+        if (e) (void)hipEventDestroy(e);
+    cleanup();
+    if (rc) return fail(MIOPAL_ERR_HIP, "host to device copy failed: %s", hipGetErrorString(hipGetLastError()));
     return 0;
 }
 
@@ -415,15 +466,15 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
         HIP_TRY(hipMalloc(&v->d_groupChunks, groupChunks.size() * sizeof(int)));
         HIP_TRY(hipMalloc(&v->d_boundaryOff, boundaryOff.size() * sizeof(int64_t)));
         HIP_TRY(hipMalloc(&d_chunkPrefix, chunkPrefix.size() * sizeof(int64_t)));
-        HIP_TRY(hipMemcpy(v->d_ids, ids.data(), ids.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        RC_TRY(uploadOnce(v->d_ids, ids.data(), ids.size() * sizeof(int32_t)));
         std::vector<int32_t> lens((size_t)v->nGroups * kGroupTargets, 0);
         for (size_t k = 0; k < ids.size(); ++k) lens[k] = dbLen(db, ids[k]);
         HIP_TRY(hipMalloc(&v->d_lens, lens.size() * sizeof(int32_t)));
-        HIP_TRY(hipMemcpy(v->d_lens, lens.data(), lens.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(v->d_groupChunks, groupChunks.data(), groupChunks.size() * sizeof(int), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(v->d_boundaryOff, boundaryOff.data(), boundaryOff.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d_chunkPrefix, chunkPrefix.data(), chunkPrefix.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        RC_TRY(uploadOnce(v->d_lens, lens.data(), lens.size() * sizeof(int32_t)));
+        RC_TRY(uploadOnce(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t)));
+        RC_TRY(uploadOnce(v->d_groupChunks, groupChunks.data(), groupChunks.size() * sizeof(int)));
+        RC_TRY(uploadOnce(v->d_boundaryOff, boundaryOff.data(), boundaryOff.size() * sizeof(int64_t)));
+        RC_TRY(uploadOnce(d_chunkPrefix, chunkPrefix.data(), chunkPrefix.size() * sizeof(int64_t)));
         PackArgs pa{};
         pa.residues = db->d_residues;
         pa.offsets = db->d_offsets;
@@ -501,8 +552,8 @@ struct Search {
         d_query = (uint8_t*)p;
         RC_TRY(ws->get(kMatrix, (size_t)A * A * sizeof(int32_t), &p));
         d_matrix = (int32_t*)p;
-        RC_TRY(upload(d_query, query, (size_t)Q, stream));
-        RC_TRY(upload(d_matrix, (const int32_t*)matrix, (size_t)A * A, stream));
+        RC_TRY(ws->stageUpload(d_query, query, (size_t)Q, stream));
+        RC_TRY(ws->stageUpload(d_matrix, matrix, (size_t)A * A * sizeof(int32_t), stream));
         return 0;
     }
 
@@ -541,7 +592,7 @@ struct Search {
         RC_TRY(ws->get(kJobs + slotBase, jobs.size() * sizeof(PairJob), &pj));
         RC_TRY(ws->get(kPairB0 + slotBase, (size_t)wsElems * sizeof(int2), &b0));
         RC_TRY(ws->get(kPairB1 + slotBase, (size_t)wsElems * sizeof(int2), &b1));
-        RC_TRY(upload((PairJob*)pj, jobs.data(), jobs.size(), on));
+        RC_TRY(ws->stageUpload(pj, jobs.data(), jobs.size() * sizeof(PairJob), on));
         IntraseqArgs a{};
         a.jobs = (const PairJob*)pj;
         a.nJobs = (int)jobs.size();
@@ -716,7 +767,7 @@ struct Search {
             RC_TRY(ws->get(kViewScore, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vs));
             RC_TRY(ws->get(kViewOvf, (size_t)view->nGroups * kGroupTargets, &vo));
             RC_TRY(ws->get(kCounter, sizeof(int32_t), &ct));
-            RC_TRY(upload((int16_t*)pp, prof.data(), prof.size(), stream));
+            RC_TRY(ws->stageUpload(pp, prof.data(), prof.size() * sizeof(prof[0]), stream));
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
             const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
             const int64_t limit = halfFloat ? 2048 : 32767;
@@ -801,8 +852,8 @@ struct Search {
             }
             if (mayOverflow) {
                 int32_t count = 0;
-                RC_TRY(download(&count, (const int32_t*)ct, 1, stream));
-                HIP_TRY(hipStreamSynchronize(stream));
+                RC_TRY(ws->stageDownload(&count, ct, sizeof(int32_t)));
+                RC_TRY(ws->finishDownloads());
                 if (halfFloat && count > kMaxDirectRecompute) {
                     // many targets left the half-float range: second rung, int16 lanes,
                     // over the whole view (its results overwrite the first pass)
@@ -810,8 +861,8 @@ struct Search {
                 }
                 if (count > 0) {
                     std::vector<uint8_t> flags((size_t)view->nPacked);
-                    RC_TRY(download(flags.data(), (const uint8_t*)vo, flags.size(), stream));
-                    HIP_TRY(hipStreamSynchronize(stream));
+                    RC_TRY(ws->stageDownload(flags.data(), vo, flags.size()));
+                    RC_TRY(ws->finishDownloads());
                     for (int k = firstPos; k < view->nPacked; ++k)
                         if (flags[k]) jobs.push_back(forwardJob(view->ids[k], rules));
                 }
@@ -861,8 +912,8 @@ int createCommon(MiopalDb** out, const unsigned char* residues, const std::vecto
             return fail(MIOPAL_ERR_BAD_ARGUMENT, "residue %d out of range for alphabet %d", residues[i], alphabetLength);
     HIP_TRY(hipMalloc(&db->d_residues, (size_t)db->total + 64));
     HIP_TRY(hipMalloc(&db->d_offsets, (size_t)(count + 1) * sizeof(int64_t)));
-    if (db->total) HIP_TRY(hipMemcpy(db->d_residues, residues, (size_t)db->total, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db->d_offsets, offsets.data(), (size_t)(count + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    RC_TRY(uploadOnce(db->d_residues, residues, (size_t)db->total));
+    RC_TRY(uploadOnce(db->d_offsets, offsets.data(), (size_t)(count + 1) * sizeof(int64_t)));
     *out = db.release();
     return 0;
 }
@@ -1148,14 +1199,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             // the operations while the host turns lengths into offsets
             int mismatch = 0;
             int64_t total = 0;
-            std::unique_ptr<int32_t[]> tscore(new int32_t[(size_t)n]);
-            std::unique_ptr<int32_t[]> lens(new int32_t[(size_t)n]);
+            // (host scratch kept on the workspace: no malloc / free of megabytes per search)
+            if (ws->hostScratchA.size() < (size_t)n) ws->hostScratchA.resize((size_t)n);
+            if (ws->hostScratchB.size() < (size_t)n) ws->hostScratchB.resize((size_t)n);
+            int32_t* const tscore = ws->hostScratchA.data();
+            int32_t* const lens = ws->hostScratchB.data();
             RC_TRY(ws->stageDownload(&total, (const int64_t*)ptotals + nBatches, sizeof(int64_t)));
             RC_TRY(ws->stageDownload(&mismatch, pmis, sizeof(int)));
-            RC_TRY(ws->stageDownload(lens.get(), plen, (size_t)n * sizeof(int32_t)));
+            RC_TRY(ws->stageDownload(lens, plen, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->stageDownload(tscore.get(), pts, (size_t)n * sizeof(int32_t)));
+            RC_TRY(ws->stageDownload(tscore, pts, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->finishDownloads());
             pt.mark("device pipeline + small D2H");
             if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
@@ -1305,7 +1359,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         RC_TRY(ws->get(kOpsOff, opsOff.size() * sizeof(int64_t), &poff));
         RC_TRY(ws->get(kOpsLen, jobs.size() * sizeof(int32_t), &plen));
         RC_TRY(ws->get(kRScore, jobs.size() * sizeof(int32_t), &pscore));
-        RC_TRY(upload((int64_t*)poff, opsOff.data(), opsOff.size(), stream));
+        RC_TRY(ws->stageUpload(poff, opsOff.data(), opsOff.size() * sizeof(int64_t), stream));
         RC_TRY(s.runPairs(jobs, true, (int32_t*)pscore, nullptr, nullptr, (uint8_t*)pd));
         WalkArgs wa{};
         void* pjobs;
