@@ -79,7 +79,13 @@ struct PhaseTimer {
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 2ll << 30;  // bytes of direction workspace per traceback batch
 constexpr int64_t kInt32Safe = 1ll << 29;
-constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
+constexpr int kMaxDirectRecompute = 2048;
+// A lane that owns a whole target walks its columns one after the other (about 0.8 us per
+// column of 56 rows): whatever the number of targets, the lane-per-target kernels need
+// (longest target) x that. Few targets of a one-strip query are done sooner by the
+// wavefront-per-pair kernel, whose anti-diagonal step is ~10x shorter and which still has a
+// wavefront for every pair at this count.
+constexpr int64_t kSmallSearch = 4096;  // saturated half-float lanes sent straight to int32
 
 // malloc-backed byte buffer: grows without zero-filling, and its storage can be handed to the
 // caller of the C ABI (who frees it with free()).
@@ -661,7 +667,7 @@ struct Search {
         std::vector<PairJob> jobs;
         RC_TRY(checkInt32(db->maxLen));
 
-        if (!interseqUsable()) {
+        if (!interseqUsable() || (Q <= kLanes && n <= kSmallSearch && !getenv("MIOPAL_NO_SMALL_SEARCH"))) {
             jobs.reserve((size_t)n);
             for (int64_t k = start; k < end; ++k) jobs.push_back(forwardJob(k, rules));
             return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
@@ -1093,7 +1099,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             }
             void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *pcompact, *pts;
             // one lane per pair (perpair.hip) instead of one wavefront per pair (intraseq.hip)
-            const bool lanePerPair = !getenv("MIOPAL_NO_PERPAIR");
+            const bool lanePerPair = !getenv("MIOPAL_NO_PERPAIR") && (n > kSmallSearch || getenv("MIOPAL_NO_SMALL_SEARCH"));
             RC_TRY(s.ensurePairInputs());
             PerPairArgs perPair{};
             perPair.residues = db->d_residues;

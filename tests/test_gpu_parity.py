@@ -61,6 +61,14 @@ with open(os.path.join(HERE, "golden", "reference_vectors.json")) as f:
 
 @pytest.mark.parametrize("vec", VECTORS, ids=[v["id"] for v in VECTORS])
 @pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_reference_vectors_small_search_routing(capi, vec, mode, small_search_routing):
+    # the reference's vectors are tiny databases: in production they take the
+    # wavefront-per-pair kernels (host.hip, kSmallSearch)
+    test_reference_vectors(capi, vec, mode)
+
+
+@pytest.mark.parametrize("vec", VECTORS, ids=[v["id"] for v in VECTORS])
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
 def test_reference_vectors(capi, vec, mode):
     m = np.array(ScoringMatrix.from_name(vec["matrix"]).int_array(), dtype=np.int32)
     q = _oracle.encode(vec["query"])

@@ -1,6 +1,8 @@
 """Randomised parity: hypothesis draws small databases, queries, matrices, gap
 penalties, modes and search types; the HIP path must agree with the CPU checker
 bit for bit on every one of them."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -58,18 +60,27 @@ def test_random_cases_match_the_checker(capi, case):
     ref = _oracle.search(query, res, off, matrix.ravel(), go, ge, mode, algo)
     db = capi.DeviceDatabase(res, off, A)
     try:
-        gpu = db.search(query, matrix.ravel(), go, ge, mode, algo)
+        # lane-per-target kernels (the tier's default), then the production routing of small
+        # searches (wavefront-per-pair kernels)
+        runs = [db.search(query, matrix.ravel(), go, ge, mode, algo)]
+        saved = os.environ.pop("MIOPAL_NO_SMALL_SEARCH", None)
+        try:
+            runs.append(db.search(query, matrix.ravel(), go, ge, mode, algo))
+        finally:
+            if saved is not None:
+                os.environ["MIOPAL_NO_SMALL_SEARCH"] = saved
     finally:
         db.close()
-    np.testing.assert_array_equal(gpu["score"], ref["score"])
-    if mode != "score":
-        np.testing.assert_array_equal(gpu["end_q"], ref["end_q"])
-        np.testing.assert_array_equal(gpu["end_t"], ref["end_t"])
-    if mode == "full":
-        np.testing.assert_array_equal(gpu["start_q"], ref["start_q"])
-        np.testing.assert_array_equal(gpu["start_t"], ref["start_t"])
-        for a, b in zip(gpu["aln"], ref["aln"]):
-            assert a.tolist() == b.tolist()
+    for gpu in runs:
+        np.testing.assert_array_equal(gpu["score"], ref["score"])
+        if mode != "score":
+            np.testing.assert_array_equal(gpu["end_q"], ref["end_q"])
+            np.testing.assert_array_equal(gpu["end_t"], ref["end_t"])
+        if mode == "full":
+            np.testing.assert_array_equal(gpu["start_q"], ref["start_q"])
+            np.testing.assert_array_equal(gpu["start_t"], ref["start_t"])
+            for a, b in zip(gpu["aln"], ref["aln"]):
+                assert a.tolist() == b.tolist()
 
 
 @st.composite
