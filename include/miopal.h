@@ -113,6 +113,16 @@ int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int query
 void miopalSetProfiling(MiopalDb* db, int enabled);
 int miopalLastKernelTime(MiopalDb* db, float* ms);
 
+/*
+ * How the score pass of the calling thread's most recent search was scheduled
+ * (diagnostics for tests and benchmarks; no reference counterpart):
+ *   counts[0] targets computed by the wavefront-per-pair (int32) kernel
+ *   counts[1] reserved (0)
+ *   counts[2] groups given to the main lane-per-target kernel
+ *   counts[3] targets recomputed because a 16-bit lane left its exact range
+ */
+void miopalLastRouting(int64_t counts[4]);
+
 /* Result-struct form, identical in shape to opalSearchDatabase but against
  * the resident mirror (what the platform plugin calls). */
 int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,

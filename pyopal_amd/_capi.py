@@ -46,7 +46,7 @@ EXPORTS = [
     "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
-    "miopalSearchResults",
+    "miopalLastRouting", "miopalSearchResults",
 ]
 
 
@@ -110,6 +110,8 @@ def lib() -> ctypes.CDLL:
                                                c_i64, c_i64, c_vp, c_vp]
         L.miopalSetProfiling.restype = None
         L.miopalSetProfiling.argtypes = [c_vp, c_int]
+        L.miopalLastRouting.restype = None
+        L.miopalLastRouting.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.miopalLastKernelTime.restype = c_int
         L.miopalLastKernelTime.argtypes = [c_vp, ctypes.POINTER(ctypes.c_float)]
         L.miopalSearchResults.restype = c_int
@@ -263,6 +265,15 @@ class DeviceDatabase:
                                             self.alphabet_length, MODE[algorithm], start, end,
                                             ctypes.c_void_p(device_ptr), ctypes.c_void_p(stream))
         raise_for(rc)
+
+    @staticmethod
+    def last_routing() -> typing.Tuple[int, int, int, int]:
+        """(targets on the wavefront-per-pair kernel, reserved, groups of 128 targets on the
+        lane-per-target kernel, targets recomputed after leaving the 16-bit range) for the
+        calling thread's most recent search."""
+        counts = (ctypes.c_int64 * 4)()
+        lib().miopalLastRouting(counts)
+        return tuple(int(c) for c in counts)
 
     def set_profiling(self, enabled: bool) -> None:
         lib().miopalSetProfiling(self._h, 1 if enabled else 0)

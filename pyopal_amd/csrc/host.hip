@@ -34,6 +34,7 @@ using namespace miopal;
 namespace {
 
 thread_local std::string g_lastError;
+thread_local int64_t g_lastRouting[4] = {0, 0, 0, 0};  // miopalLastRouting
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -667,7 +668,9 @@ struct Search {
         std::vector<PairJob> jobs;
         RC_TRY(checkInt32(db->maxLen));
 
+        g_lastRouting[0] = g_lastRouting[1] = g_lastRouting[2] = g_lastRouting[3] = 0;
         if (!interseqUsable() || (Q <= kLanes && n <= kSmallSearch && !getenv("MIOPAL_NO_SMALL_SEARCH"))) {
+            g_lastRouting[0] = n;
             jobs.reserve((size_t)n);
             for (int64_t k = start; k < end; ++k) jobs.push_back(forwardJob(k, rules));
             return runPairs(jobs, false, d_score, d_endI, d_endJ, nullptr);
@@ -701,6 +704,8 @@ struct Search {
             balancedChunks = total / std::max<int64_t>(slots, 1);
         }
         const int firstPos = std::min(firstGroup * kGroupTargets, view->nPacked);
+        g_lastRouting[0] = (int64_t)sideJobs.size();
+        g_lastRouting[2] = view->nGroups - firstGroup;
 
         if (view->nGroups > firstGroup) {
             const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
@@ -871,6 +876,7 @@ struct Search {
                     RC_TRY(ws->finishDownloads());
                     for (int k = firstPos; k < view->nPacked; ++k)
                         if (flags[k]) jobs.push_back(forwardJob(view->ids[k], rules));
+                    g_lastRouting[3] = count;
                 }
             }
         }
@@ -994,6 +1000,11 @@ int64_t miopalDbDeviceBytes(const MiopalDb* db) {
 
 void miopalSetProfiling(MiopalDb* db, int enabled) {
     if (db) db->profiling.store(enabled ? 1 : 0);
+}
+
+void miopalLastRouting(int64_t counts[4]) {
+    if (!counts) return;
+    for (int k = 0; k < 4; ++k) counts[k] = g_lastRouting[k];
 }
 
 int miopalLastKernelTime(MiopalDb* db, float* ms) {

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import _cpu_baseline
 import _data
 import _oracle
 from pyopal_amd.matrices import ScoringMatrix
@@ -298,3 +299,49 @@ def test_errors(capi):
     with pytest.raises(OverflowError):
         db.search(q, big, 3, 1, "score", "nw")
     db.close()
+
+
+@pytest.mark.parametrize("qlen", [53, 24, 64])
+def test_long_groups_beside_the_packed_kernel(capi, qlen):
+    """Variable-length database: the longest groups of a one-strip Smith-Waterman search are
+    computed by the wavefront-per-pair kernel on a side stream, the rest by the lane-per-target
+    kernel - both must agree with the checker, for scores, end locations and full alignments."""
+    rng = np.random.default_rng(100 + qlen)
+    lengths = np.clip(rng.lognormal(5.3, 0.5, size=60_000), 10, 1500).astype(np.int64)
+    lengths[rng.integers(0, len(lengths), size=700)] = rng.integers(1500, 3500, size=700)   # long groups
+    lengths[rng.integers(0, len(lengths), size=6)] = rng.integers(7000, 8100, size=6)       # extreme
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, qlen)
+    # plant a few strong hits inside long targets so that locations far from the ends are checked
+    order = np.argsort(lengths)
+    for k in order[-40:]:
+        at = off[k] + lengths[k] // 2
+        copy = _data.mutate(rng, q, 0.1)
+        m = min(len(copy), int(lengths[k] // 2))
+        res[at:at + m] = copy[:m]
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        score = db.search(q, B62, 3, 1, "score", "sw")
+        routed = capi.DeviceDatabase.last_routing()
+        assert routed[0] >= 128 and routed[2] > 0, f"expected long groups on the int32 kernel, got {routed}"
+        cpu = _cpu_baseline.CpuDatabase(res, off)
+        want = cpu.search_sw(q, B62, 3, 1, 8)
+        cpu.close()
+        np.testing.assert_array_equal(score["score"], want)
+        end = db.search(q, B62, 3, 1, "end", "sw")
+        np.testing.assert_array_equal(end["score"], want)
+        # the checker on the longest 150 targets and on a random sample
+        sample = np.unique(np.concatenate([order[-150:], rng.integers(0, len(lengths), size=300)]))
+        sub = [res[off[k]:off[k + 1]] for k in sample]
+        sres, soff = _oracle.flatten(sub)
+        ref = _oracle.search(q, sres, soff, B62, 3, 1, "full", "sw")
+        for key in ("score", "end_q", "end_t"):
+            np.testing.assert_array_equal(end[key][sample], ref[key], err_msg=key)
+        if qlen == 53:
+            full = db.search(q, B62, 3, 1, "full", "sw")
+            for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+                np.testing.assert_array_equal(full[key][sample], ref[key], err_msg=key)
+            for x, k in enumerate(sample):
+                assert full["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
+    finally:
+        db.close()
