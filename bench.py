@@ -170,6 +170,11 @@ def main():
                 "algorithmic_bytes": alg_bytes,
                 "note": "integer-VALU-bound by construction (about 4 packed VALU ops per cell, "
                         "0.02 B/cell): see DESIGN.md",
+                # secondary ceiling: VALU issue. 418 packed instructions per
+                # wavefront-column of 128 x 56 cells (SQ_INSTS_VALU, profiles/r01d_pmc_*), each
+                # ~4.42 SIMD-cycles at the instruction mix's measured issue rate
+                # (profiles/r01_valu_issue_rates.txt), 1024 SIMDs at the 2.4 GHz boost clock
+                "valu_issue": valu_ceiling(Q, k_ms, N, L),
             },
             "db_build_s": round(build_s, 3),
             "score_checksum": checksum,
@@ -181,6 +186,17 @@ def main():
     db.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def valu_ceiling(Q, kernel_ms, N, L):
+    """Cells/s the dominant kernel could reach if every SIMD issued its measured instruction
+    mix back to back: informational, next to the mandated HBM roofline."""
+    simds, clock_hz = 1024, 2.4e9
+    instr_per_column, cycles_per_instr, targets_per_wave = 418.0, 4.42, 128
+    peak = simds * clock_hz / (instr_per_column * cycles_per_instr) * targets_per_wave * Q / 1e9
+    achieved = float(Q) * N * L / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GCUPS",
+            "frac": round(achieved / peak, 3)}
 
 
 def extras(db, query, matrix, Q, N, L):
