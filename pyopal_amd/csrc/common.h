@@ -118,7 +118,9 @@ struct PackArgs {
     const uint8_t* residues;
     const int64_t* offsets;   // [N + 1] into residues
     const int32_t* ids;       // view position -> database index
-    int nTargets;             // targets in the view
+    const int32_t* segStart;  // view position -> first residue of its segment (null: whole targets)
+    const int32_t* lens;      // view position -> residues of the segment (with segStart)
+    int nTargets;             // (virtual) targets in the view
     const int64_t* groupOff;
     const int* groupChunks;
     const int64_t* chunkPrefix;  // [nGroups + 1] running number of chunks
@@ -171,9 +173,10 @@ hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const
 hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
                              int rules, PairJob* jobs, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
+// takeMax: several view positions (segments) may belong to one target; `out` starts at 0
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,
-                         hipStream_t stream);
+                         bool takeMax, hipStream_t stream);
 hipError_t launchScatterEnds(const int32_t* viewEndI, const int32_t* viewEndJ, const int32_t* ids,
                              int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ,
                              hipStream_t stream);

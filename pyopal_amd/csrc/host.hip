@@ -283,6 +283,8 @@ struct Workspace {
 // ---------------------------------------------------------------------------
 struct View {
     int64_t start = 0, end = 0;
+    int overlap = 0;                 // > 0: long targets are cut into windows overlapping by this much
+    int32_t* d_segStart = nullptr;   // view position -> first residue of its window (segmented views)
     int nPacked = 0;                 // targets in the packed groups
     int nGroups = 0;
     int maxPackedLen = 0;
@@ -299,6 +301,7 @@ struct View {
     size_t deviceBytes = 0;
     ~View() {
         if (d_ids) (void)hipFree(d_ids);
+        if (d_segStart) (void)hipFree(d_segStart);
         if (d_lens) (void)hipFree(d_lens);
         if (d_pack) (void)hipFree(d_pack);
         if (d_groupOff) (void)hipFree(d_groupOff);
@@ -435,25 +438,64 @@ int uploadOnce(void* deviceDst, const void* src, size_t bytes) {
 int dbLen(const MiopalDb* db, int64_t id) { return (int)(db->offsets[id + 1] - db->offsets[id]); }
 
 // ---- view construction -------------------------------------------------------
-int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* out) {
+// Window stride of a segmented view: with overlap O (>= the longest span a local alignment of the
+// query can have in the target) every alignment lies inside one window [k S, k S + S + O).
+int segmentStride(int overlap) { return std::max(256, (overlap * 3 / 5 + 63) / 64 * 64); }
+
+int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
     auto v = std::make_shared<View>();
     v->start = start;
     v->end = end;
-    std::vector<int32_t> ids;
+    v->overlap = overlap;
+    std::vector<int32_t> ids, segStart, vlen;
     ids.reserve((size_t)(end - start));
-    for (int64_t k = start; k < end; ++k) {
-        if (dbLen(db, k) > kLongTarget) v->longIds.push_back((int32_t)k);
-        else ids.push_back((int32_t)k);
+    if (overlap > 0) {
+        const int stride = segmentStride(overlap), window = stride + overlap;
+        for (int64_t k = start; k < end; ++k) {
+            const int L = dbLen(db, k);
+            if (L <= window) {
+                ids.push_back((int32_t)k);
+                segStart.push_back(0);
+                vlen.push_back(L);
+                continue;
+            }
+            // windows until the tail is inside the overlap of the previous one
+            for (int s = 0; s == 0 || L - s > overlap; s += stride) {
+                ids.push_back((int32_t)k);
+                segStart.push_back(s);
+                vlen.push_back(std::min(window, L - s));
+            }
+        }
+        // longest first (stable: windows of one target stay in order)
+        std::vector<int32_t> order(ids.size());
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return vlen[a] > vlen[b]; });
+        std::vector<int32_t> ids2(ids.size()), seg2(ids.size()), len2(ids.size());
+        for (size_t x = 0; x < order.size(); ++x) {
+            ids2[x] = ids[order[x]];
+            seg2[x] = segStart[order[x]];
+            len2[x] = vlen[order[x]];
+        }
+        ids.swap(ids2);
+        segStart.swap(seg2);
+        vlen.swap(len2);
+    } else {
+        for (int64_t k = start; k < end; ++k) {
+            if (dbLen(db, k) > kLongTarget) v->longIds.push_back((int32_t)k);
+            else ids.push_back((int32_t)k);
+        }
+        // longest first: the heaviest wavefronts are dispatched first
+        std::stable_sort(ids.begin(), ids.end(),
+                         [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
+        vlen.resize(ids.size());
+        for (size_t k = 0; k < ids.size(); ++k) vlen[k] = dbLen(db, ids[k]);
     }
-    // longest first: the heaviest wavefronts are dispatched first
-    std::stable_sort(ids.begin(), ids.end(),
-                     [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
     v->nPacked = (int)ids.size();
     v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
     std::vector<int64_t> groupOff(v->nGroups + 1, 0), chunkPrefix(v->nGroups + 1, 0), boundaryOff(v->nGroups + 1, 0);
     std::vector<int> groupChunks(std::max(v->nGroups, 1), 0);
     for (int g = 0; g < v->nGroups; ++g) {
-        const int maxLen = dbLen(db, ids[(size_t)g * kGroupTargets]);  // sorted: first is longest
+        const int maxLen = vlen[(size_t)g * kGroupTargets];  // sorted: first is longest
         v->maxPackedLen = std::max(v->maxPackedLen, maxLen);
         const int chunks = std::max(1, (maxLen + 3) / 4);
         groupChunks[g] = chunks;
@@ -475,7 +517,11 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
         HIP_TRY(hipMalloc(&d_chunkPrefix, chunkPrefix.size() * sizeof(int64_t)));
         RC_TRY(uploadOnce(v->d_ids, ids.data(), ids.size() * sizeof(int32_t)));
         std::vector<int32_t> lens((size_t)v->nGroups * kGroupTargets, 0);
-        for (size_t k = 0; k < ids.size(); ++k) lens[k] = dbLen(db, ids[k]);
+        for (size_t k = 0; k < ids.size(); ++k) lens[k] = vlen[k];
+        if (overlap > 0) {
+            HIP_TRY(hipMalloc(&v->d_segStart, segStart.size() * sizeof(int32_t)));
+            RC_TRY(uploadOnce(v->d_segStart, segStart.data(), segStart.size() * sizeof(int32_t)));
+        }
         HIP_TRY(hipMalloc(&v->d_lens, lens.size() * sizeof(int32_t)));
         RC_TRY(uploadOnce(v->d_lens, lens.data(), lens.size() * sizeof(int32_t)));
         RC_TRY(uploadOnce(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t)));
@@ -486,6 +532,8 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
         pa.residues = db->d_residues;
         pa.offsets = db->d_offsets;
         pa.ids = v->d_ids;
+        pa.segStart = v->d_segStart;
+        pa.lens = v->d_lens;
         pa.nTargets = v->nPacked;
         pa.groupOff = v->d_groupOff;
         pa.groupChunks = v->d_groupChunks;
@@ -502,16 +550,16 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* o
     return 0;
 }
 
-int getView(MiopalDb* db, int64_t start, int64_t end, std::shared_ptr<View>* out) {
+int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
     std::lock_guard<std::mutex> g(db->viewMutex);
     for (auto it = db->views.begin(); it != db->views.end(); ++it) {
-        if ((*it)->start == start && (*it)->end == end) {
+        if ((*it)->start == start && (*it)->end == end && (*it)->overlap == overlap) {
             *out = *it;
             db->views.splice(db->views.begin(), db->views, it);
             return 0;
         }
     }
-    RC_TRY(buildView(db, start, end, out));
+    RC_TRY(buildView(db, start, end, overlap, out));
     db->views.push_front(*out);
     // keep the full-database view plus a few slices (thread-chunked callers,
     // src/pyopal/_align.py:150-170, re-use their slice on every query)
@@ -677,12 +725,34 @@ struct Search {
         }
 
         PhaseTimer spt;
+        // Smith-Waterman, scores only: long targets can be searched as overlapping windows. A
+        // local alignment with a positive score has at most Q aligned pairs and, each gap
+        // column costing at least min(open, ext), at most Q * max(S) / min(open, ext) gap
+        // columns, so it spans at most that many target columns (`reach`): with windows that
+        // overlap by `reach` every alignment lies inside one of them, and the maximum over a
+        // target's windows is its score. No window is longer than stride + overlap, so no
+        // target has to leave the packed kernel for the 14x dearer wavefront-per-pair kernel.
+        int overlap = 0;
+        if (mode == OPAL_MODE_SW && searchType == OPAL_SEARCH_SCORE && std::min(open, ext) > 0 && maxScore > 0 &&
+            !getenv("MIOPAL_NO_SEGMENTS")) {
+            const int64_t reach = Q + (int64_t)Q * maxScore / std::min(open, ext) + 1;
+            const int64_t rounded = (reach + 63) / 64 * 64;
+            if (rounded <= 2048 && db->maxLen > segmentStride((int)rounded) + rounded) overlap = (int)rounded;
+        }
         std::shared_ptr<View> view;
-        RC_TRY(getView(db, start, end, &view));
+        RC_TRY(getView(db, start, end, overlap, &view));
         spt.mark("    view lookup");
         // not handled by the packed kernel: can be recomputed beside it
         std::vector<PairJob> sideJobs;
         for (int32_t id : view->longIds) sideJobs.push_back(forwardJob(id, rules));
+        // windows of one target are merged with atomicMax: start from 0 (Smith-Waterman scores
+        // are never negative); whole-target results of the int32 kernel are plain stores of the
+        // final value, in either order the maximum is that value
+        if (overlap > 0) HIP_TRY(hipMemsetAsync(d_score, 0, (size_t)n * sizeof(int32_t), stream));
+        // (a target whose windows are neighbours in the view is queued once)
+        auto queueWhole = [&](std::vector<PairJob>& list, int32_t id) {
+            if (list.empty() || list.back().out != (int32_t)(id - start)) list.push_back(forwardJob(id, rules));
+        };
 
         const int nStrips = std::max(1, (Q + kMaxStripRows - 1) / kMaxStripRows);
         // strips of a group in flight (wavefronts per workgroup)
@@ -697,10 +767,12 @@ struct Search {
             int64_t total = 0;
             for (int c : view->groupChunksHost) total += c;
             const int64_t slots = (int64_t)db->computeUnits * std::max(1, 12 / waves);
-            const int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
+            int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
+            // windows of a segmented view are as short as a group of long targets can get
+            if (overlap > 0) limit = std::max<int64_t>(limit, (segmentStride(overlap) + overlap + 3) / 4);
             while (firstGroup < view->nGroups && view->groupChunksHost[firstGroup] > limit) ++firstGroup;
             const int skipped = std::min(firstGroup * kGroupTargets, view->nPacked);
-            for (int k = 0; k < skipped; ++k) sideJobs.push_back(forwardJob(view->ids[k], rules));
+            for (int k = 0; k < skipped; ++k) queueWhole(sideJobs, view->ids[k]);
             balancedChunks = total / std::max<int64_t>(slots, 1);
         }
         const int firstPos = std::min(firstGroup * kGroupTargets, view->nPacked);
@@ -851,7 +923,7 @@ struct Search {
             }
             const int nScatter = view->nPacked - firstPos;
             HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos, nScatter,
-                                  start, d_score, mayOverflow ? (int32_t*)ct : nullptr, stream));
+                                  start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0, stream));
             if (locate)
                 HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos, nScatter,
                                           start, d_endI, d_endJ, stream));
@@ -875,7 +947,7 @@ struct Search {
                     RC_TRY(ws->stageDownload(flags.data(), vo, flags.size()));
                     RC_TRY(ws->finishDownloads());
                     for (int k = firstPos; k < view->nPacked; ++k)
-                        if (flags[k]) jobs.push_back(forwardJob(view->ids[k], rules));
+                        if (flags[k]) queueWhole(jobs, view->ids[k]);
                     g_lastRouting[3] = count;
                 }
             }

@@ -52,11 +52,19 @@ __global__ void pack_kernel(PackArgs a) {
         const int id = a.ids[posA];
         pa = a.residues + a.offsets[id];
         la = a.offsets[id + 1] - a.offsets[id];
+        if (a.segStart) {  // a window of a long target
+            pa += a.segStart[posA];
+            la = a.lens[posA];
+        }
     }
     if (posB < a.nTargets) {
         const int id = a.ids[posB];
         pb = a.residues + a.offsets[id];
         lb = a.offsets[id + 1] - a.offsets[id];
+        if (a.segStart) {
+            pb += a.segStart[posB];
+            lb = a.lens[posB];
+        }
     }
     const uint32_t pad = (uint32_t)a.padSymbol;
     a.pack[a.groupOff[g] + chunk * kLanes + lane] =
@@ -64,12 +72,15 @@ __global__ void pack_kernel(PackArgs a) {
 }
 
 // view order -> database order (relative to the slice start); counts saturated lanes
+template <bool TAKE_MAX>
 __global__ void scatter_kernel(const int32_t* viewScore, const uint8_t* viewOverflow,
                                const int32_t* ids, int nTargets, int64_t sliceStart,
                                int32_t* out, int32_t* overflowCount) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nTargets) return;
-    out[ids[k] - sliceStart] = viewScore[k];
+    // segmented views: a target's score is the maximum over its overlapping windows
+    if (TAKE_MAX) atomicMax(&out[ids[k] - sliceStart], viewScore[k]);
+    else out[ids[k] - sliceStart] = viewScore[k];
     if (overflowCount != nullptr && viewOverflow[k]) atomicAdd(overflowCount, 1);
 }
 
@@ -102,11 +113,16 @@ hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream
 
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,
-                         hipStream_t stream) {
+                         bool takeMax, hipStream_t stream) {
     if (nTargets <= 0) return hipSuccess;
     const int threads = 256;
-    hipLaunchKernelGGL(scatter_kernel, dim3((nTargets + threads - 1) / threads), dim3(threads), 0, stream,
-                       viewScore, viewOverflow, ids, nTargets, sliceStart, out, overflowCount);
+    const dim3 grid((nTargets + threads - 1) / threads);
+    if (takeMax)
+        hipLaunchKernelGGL(scatter_kernel<true>, grid, dim3(threads), 0, stream, viewScore, viewOverflow, ids,
+                           nTargets, sliceStart, out, overflowCount);
+    else
+        hipLaunchKernelGGL(scatter_kernel<false>, grid, dim3(threads), 0, stream, viewScore, viewOverflow, ids,
+                           nTargets, sliceStart, out, overflowCount);
     return hipGetLastError();
 }
 

@@ -323,12 +323,15 @@ def test_long_groups_beside_the_packed_kernel(capi, qlen):
     try:
         score = db.search(q, B62, 3, 1, "score", "sw")
         routed = capi.DeviceDatabase.last_routing()
-        assert routed[0] >= 128 and routed[2] > 0, f"expected long groups on the int32 kernel, got {routed}"
+        # scores only: long targets are searched as overlapping windows inside the packed kernel
+        assert routed[2] > 0 and routed[0] < 128, f"expected a segmented view, got {routed}"
         cpu = _cpu_baseline.CpuDatabase(res, off)
         want = cpu.search_sw(q, B62, 3, 1, 8)
         cpu.close()
         np.testing.assert_array_equal(score["score"], want)
         end = db.search(q, B62, 3, 1, "end", "sw")
+        routed = capi.DeviceDatabase.last_routing()
+        assert routed[0] >= 128 and routed[2] > 0, f"expected long groups on the int32 kernel, got {routed}"
         np.testing.assert_array_equal(end["score"], want)
         # the checker on the longest 150 targets and on a random sample
         sample = np.unique(np.concatenate([order[-150:], rng.integers(0, len(lengths), size=300)]))
@@ -343,5 +346,42 @@ def test_long_groups_beside_the_packed_kernel(capi, qlen):
                 np.testing.assert_array_equal(full[key][sample], ref[key], err_msg=key)
             for x, k in enumerate(sample):
                 assert full["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("qlen,gaps,matrix", [(53, (3, 1), "B62"), (20, (3, 1), "B62"), (64, (11, 1), "B50"),
+                                                (53, (1, 2), "B62"), (40, (5, 2), "B62"), (53, (3, 0), "B62"),
+                                                (120, (3, 1), "B62")])
+def test_segmented_views_every_score(capi, qlen, gaps, matrix):
+    """Smith-Waterman scores of long targets as the maximum over overlapping windows
+    (host.hip, `overlap`): every score equals the CPU baseline's, for several window sizes
+    (the reach Q + Q max(S) / min(open, ext) varies), with targets beyond the packed kernel's
+    usual length limit, and for a gap model that rules segmentation out (ext = 0)."""
+    rng = np.random.default_rng(7 * qlen + gaps[0])
+    lengths = np.clip(rng.lognormal(5.3, 0.6, size=30_000), 5, 2500).astype(np.int64)
+    lengths[rng.integers(0, len(lengths), size=300)] = rng.integers(2500, 8100, size=300)
+    lengths[rng.integers(0, len(lengths), size=4)] = [9000, 12_345, 8193, 20_000]
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, qlen)
+    order = np.argsort(lengths)
+    for k in order[-60:]:     # strong hits at random places of the longest targets, some across window borders
+        copy = _data.mutate(rng, q, 0.15)
+        at = int(rng.integers(0, max(1, lengths[k] - len(copy))))
+        m = min(len(copy), int(lengths[k]) - at)
+        res[off[k] + at:off[k] + at + m] = copy[:m]
+    mat = B62 if matrix == "B62" else B50
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(q, mat, gaps[0], gaps[1], "score", "sw")["score"]
+        routed = capi.DeviceDatabase.last_routing()
+        cpu = _cpu_baseline.CpuDatabase(res, off)
+        want = cpu.search_sw(q, mat, gaps[0], gaps[1], 8)
+        cpu.close()
+        np.testing.assert_array_equal(got, want)
+        if gaps[1] > 0 and qlen <= 64:
+            assert routed[0] < 64, f"long targets should stay in the packed kernel, got {routed}"
+        part = db.search(q, mat, gaps[0], gaps[1], "score", "sw", 1000, 20_000)["score"]
+        np.testing.assert_array_equal(part, want[1000:20_000])
     finally:
         db.close()
