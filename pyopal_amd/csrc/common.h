@@ -173,6 +173,13 @@ hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const
 hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
                              int rules, PairJob* jobs, hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
+// segmented views with end locations (pack.hip): keyed atomicMax per window, then unpack
+hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
+                              const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
+                              int nTargets, int64_t sliceStart, unsigned long long* keys, int32_t* overflowCount,
+                              hipStream_t stream);
+hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
+                            hipStream_t stream);
 // takeMax: several view positions (segments) may belong to one target; `out` starts at 0
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,

@@ -143,7 +143,7 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kSlots
 };
 
 struct Workspace {
@@ -725,7 +725,7 @@ struct Search {
         }
 
         PhaseTimer spt;
-        // Smith-Waterman, scores only: long targets can be searched as overlapping windows. A
+        // Smith-Waterman: long targets can be searched as overlapping windows. A
         // local alignment with a positive score has at most Q aligned pairs and, each gap
         // column costing at least min(open, ext), at most Q * max(S) / min(open, ext) gap
         // columns, so it spans at most that many target columns (`reach`): with windows that
@@ -733,8 +733,8 @@ struct Search {
         // target's windows is its score. No window is longer than stride + overlap, so no
         // target has to leave the packed kernel for the 14x dearer wavefront-per-pair kernel.
         int overlap = 0;
-        if (mode == OPAL_MODE_SW && searchType == OPAL_SEARCH_SCORE && std::min(open, ext) > 0 && maxScore > 0 &&
-            !getenv("MIOPAL_NO_SEGMENTS")) {
+        if (mode == OPAL_MODE_SW && std::min(open, ext) > 0 && maxScore > 0 && (int64_t)Q * maxScore < (1 << 23) &&
+            Q < 65536 && db->maxLen < (1 << 24) && !getenv("MIOPAL_NO_SEGMENTS")) {
             const int64_t reach = Q + (int64_t)Q * maxScore / std::min(open, ext) + 1;
             const int64_t rounded = (reach + 63) / 64 * 64;
             if (rounded <= 2048 && db->maxLen > segmentStride((int)rounded) + rounded) overlap = (int)rounded;
@@ -748,7 +748,14 @@ struct Search {
         // windows of one target are merged with atomicMax: start from 0 (Smith-Waterman scores
         // are never negative); whole-target results of the int32 kernel are plain stores of the
         // final value, in either order the maximum is that value
-        if (overlap > 0) HIP_TRY(hipMemsetAsync(d_score, 0, (size_t)n * sizeof(int32_t), stream));
+        const bool keyed = overlap > 0 && searchType != OPAL_SEARCH_SCORE;  // with end locations
+        void* keys = nullptr;
+        if (keyed) {
+            RC_TRY(ws->get(kKeys, (size_t)n * sizeof(unsigned long long), &keys));
+            HIP_TRY(hipMemsetAsync(keys, 0, (size_t)n * sizeof(unsigned long long), stream));
+        } else if (overlap > 0) {
+            HIP_TRY(hipMemsetAsync(d_score, 0, (size_t)n * sizeof(int32_t), stream));
+        }
         // (a target whose windows are neighbours in the view is queued once)
         auto queueWhole = [&](std::vector<PairJob>& list, int32_t id) {
             if (list.empty() || list.back().out != (int32_t)(id - start)) list.push_back(forwardJob(id, rules));
@@ -922,11 +929,23 @@ struct Search {
                 db->lastTimed = ws;
             }
             const int nScatter = view->nPacked - firstPos;
-            HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos, nScatter,
-                                  start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0, stream));
-            if (locate)
-                HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos, nScatter,
-                                          start, d_endI, d_endJ, stream));
+            if (keyed) {
+                // nothing else writes the results of a segmented search before this point: no
+                // target is kept out of the view, no group is skipped (limit >= one window)
+                if (firstPos != 0 || !sideJobs.empty() || forked)
+                    return fail(MIOPAL_ERR_INTERNAL, "segmented view with side jobs");
+                HIP_TRY(launchScatterKeyed(ia.score, ia.endI, ia.endJ, (const uint8_t*)vo, view->d_ids,
+                                           view->d_segStart, nScatter, start, (unsigned long long*)keys,
+                                           mayOverflow ? (int32_t*)ct : nullptr, stream));
+                HIP_TRY(launchDecodeKeys((const unsigned long long*)keys, (int)n, d_score, d_endI, d_endJ, stream));
+            } else {
+                HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos,
+                                      nScatter, start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0,
+                                      stream));
+                if (locate)
+                    HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos,
+                                              nScatter, start, d_endI, d_endJ, stream));
+            }
             if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws->evJoin, 0));
             spt.mark("    packed kernel enqueued");
             if (spt.on) {
@@ -1165,11 +1184,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     // (start cells, traceback jobs, direction bytes and operations are produced and
     // consumed on the device; the host only prefix-sums the alignment lengths)
     {
-        // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
-        const int64_t slotDir = (db->maxLen + kLanes - 1) * kLanes;
-        const int64_t slotOps = (queryLength + db->maxLen + 3) & ~(int64_t)3;  // operations of one pair
-        const bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
-                                n * slotOps <= (8ll << 30) && !getenv("MIOPAL_HOST_TRACEBACK");
+        bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
+                          !getenv("MIOPAL_HOST_TRACEBACK");
         if (deviceFull) {
             HostBytes localOps;
             std::vector<int64_t> localOff;
@@ -1195,11 +1211,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             RC_TRY(ws->get(kStartQ, (size_t)n * sizeof(int32_t), &psq));
             RC_TRY(ws->get(kStartT, (size_t)n * sizeof(int32_t), &pst));
-            RC_TRY(ws->get(kMismatch, sizeof(int), &pmis));
+            RC_TRY(ws->get(kMismatch, 2 * sizeof(int), &pmis));
             RC_TRY(ws->get(kOpsLen, (size_t)n * sizeof(int32_t), &plen));
-            RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
             RC_TRY(ws->get(kRScore, (size_t)n * sizeof(int32_t), &rs));
-            HIP_TRY(hipMemsetAsync(pmis, 0, sizeof(int), stream));
+            HIP_TRY(hipMemsetAsync(pmis, 0, 2 * sizeof(int), stream));
             if (mode != OPAL_MODE_NW) {
                 RC_TRY(ws->get(kRI, (size_t)n * sizeof(int32_t), &ri));
                 RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
@@ -1223,14 +1238,29 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                                      (const int32_t*)pj, (const int32_t*)rs, (const int32_t*)ri, (const int32_t*)rj,
                                      (int32_t*)psq, (int32_t*)pst, (int*)pmis, stream));
             pt.mark("start cells (enqueued)");
+            // The slots of the traceback are sized by the longest target window of the slice
+            // (local alignments are short whatever the targets' lengths): one small D2H + sync.
+            int checks[2] = {0, 0};
+            RC_TRY(ws->stageDownload(checks, pmis, sizeof checks));
+            RC_TRY(ws->finishDownloads());
+            if (checks[0])
+                return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
+                            (long long)(start + checks[0] - 1));
+            const int64_t maxWindow = std::max(checks[1], 1);
+            // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
+            const int64_t slotDir = (maxWindow + kLanes - 1) * kLanes;
+            const int64_t slotOps = (queryLength + maxWindow + 3) & ~(int64_t)3;  // operations of one pair
+            if (n * slotOps > (16ll << 30)) deviceFull = false;  // host-built batches below
+          if (deviceFull) {
+            RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
             // traceback in batches of whole direction slots
             // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
             const int64_t batch =
                 std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
             void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
-            const bool sortJobs = lanePerPair && db->maxLen <= kLongTarget;  // bins live in LDS
+            const bool sortJobs = lanePerPair && maxWindow <= kLongTarget;  // bins live in LDS
             if (sortJobs) {
-                RC_TRY(ws->get(kSortBins, (size_t)(db->maxLen + 1) * sizeof(int), &pbins));
+                RC_TRY(ws->get(kSortBins, (size_t)(maxWindow + 1) * sizeof(int), &pbins));
                 RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
             }
             RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
@@ -1252,7 +1282,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 if (lanePerPair) {
                     // neighbours of similar length share a wavefront; results stay addressed by job.out
                     if (sortJobs) {
-                        HIP_TRY(launchSortJobsByLength(jobs, nb, (int)db->maxLen, (int*)pbins, (PairJob*)psorted,
+                        HIP_TRY(launchSortJobsByLength(jobs, nb, (int)maxWindow, (int*)pbins, (PairJob*)psorted,
                                                        stream));
                         jobs = (PairJob*)psorted;
                         wa.slotByOut = 1;
@@ -1286,7 +1316,6 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             pt.mark("traceback batches (enqueued)");
             // results back to the host: the small arrays first (they carry the total size),
             // the operations while the host turns lengths into offsets
-            int mismatch = 0;
             int64_t total = 0;
             // (host scratch kept on the workspace: no malloc / free of megabytes per search)
             if (ws->hostScratchA.size() < (size_t)n) ws->hostScratchA.resize((size_t)n);
@@ -1294,7 +1323,6 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             int32_t* const tscore = ws->hostScratchA.data();
             int32_t* const lens = ws->hostScratchB.data();
             RC_TRY(ws->stageDownload(&total, (const int64_t*)ptotals + nBatches, sizeof(int64_t)));
-            RC_TRY(ws->stageDownload(&mismatch, pmis, sizeof(int)));
             RC_TRY(ws->stageDownload(lens, plen, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
             RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
@@ -1309,9 +1337,6 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
             RC_TRY(ws->finishDownloads());
             pt.mark("operations D2H");
-            if (mismatch)
-                return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
-                            (long long)(start + mismatch - 1));
             for (int64_t k = 0; k < n; ++k)
                 if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k])
                     return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
@@ -1330,6 +1355,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             }
             pt.mark("host copy-out");
             return 0;
+          }
         }
     }
 

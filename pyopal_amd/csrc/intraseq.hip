@@ -319,9 +319,12 @@ __global__ void start_cells_kernel(int n, int mode, int open, int ext, const int
                                    const int32_t* endQ, const int32_t* endT, const int32_t* rScore,
                                    const int32_t* rI, const int32_t* rJ, int32_t* startQ,
                                    int32_t* startT, int* mismatch) {
+    // mismatch[0]: 1 + index of a slot whose reverse pass disagrees; mismatch[1]: longest target
+    // window of the slice (sizes the direction and operation slots of the traceback)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int qe = endQ[k], te = endT[k];
+    int window = 0;
+    const bool live = k < n;
+    const int qe = live ? endQ[k] : -1, te = live ? endT[k] : -1;
     int sq = -1, st = -1;
     if (qe >= 0 && te >= 0) {
         if (mode == 0 /* NW */) {
@@ -345,9 +348,15 @@ __global__ void start_cells_kernel(int n, int mode, int open, int ext, const int
             sq = qe - ri;
             st = te - rj;
         }
+        window = te - st + 1;
     }
-    startQ[k] = sq;
-    startT[k] = st;
+    if (live) {
+        startQ[k] = sq;
+        startT[k] = st;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) window = max(window, __shfl_xor(window, off));
+    if ((threadIdx.x & 63) == 0 && window > 0) atomicMax(&mismatch[1], window);
 }
 
 // Traceback jobs on the [start..end] rectangles; job k owns direction slot k.

@@ -93,6 +93,57 @@ __global__ void scatter_ends_kernel(const int32_t* viewEndI, const int32_t* view
     outJ[slot] = viewEndJ[k];
 }
 
+// Segmented views with end locations: the end cell of a target is the first maximum of the
+// column-major scan over the whole target = highest score, then smallest end column, then
+// smallest row among its windows' own first maxima (a window holding an optimal alignment
+// reports exactly the target's end cell, no window reports a cell that is not an optimum of
+// the whole target). One 64-bit atomicMax per window on
+//     score << 40 | (2^24 - 1 - column) << 16 | (2^16 - 1 - row)
+// into zero-initialised keys, then a pass that unpacks them.
+__global__ void scatter_keyed_kernel(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
+                                     const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
+                                     int nTargets, int64_t sliceStart, unsigned long long* keys,
+                                     int32_t* overflowCount) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nTargets) return;
+    if (overflowCount != nullptr && viewOverflow[k]) atomicAdd(overflowCount, 1);
+    const int score = viewScore[k];
+    if (score <= 0 || viewEndJ[k] < 0) return;
+    const unsigned long long col = (unsigned long long)(segStart[k] + viewEndJ[k]);
+    const unsigned long long row = (unsigned long long)viewEndI[k];
+    const unsigned long long key =
+        ((unsigned long long)score << 40) | ((0xFFFFFFull - col) << 16) | (0xFFFFull - row);
+    atomicMax(&keys[ids[k] - sliceStart], key);
+}
+
+__global__ void decode_keys_kernel(const unsigned long long* keys, int n, int32_t* score, int32_t* endI,
+                                   int32_t* endJ) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long key = keys[k];
+    const int s = (int)(key >> 40);
+    score[k] = s;
+    endI[k] = s > 0 ? (int)(0xFFFFull - (key & 0xFFFFull)) : -1;
+    endJ[k] = s > 0 ? (int)(0xFFFFFFull - ((key >> 16) & 0xFFFFFFull)) : -1;
+}
+
+hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
+                              const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
+                              int nTargets, int64_t sliceStart, unsigned long long* keys, int32_t* overflowCount,
+                              hipStream_t stream) {
+    if (nTargets <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_keyed_kernel, dim3((nTargets + 255) / 256), dim3(256), 0, stream, viewScore,
+                       viewEndI, viewEndJ, viewOverflow, ids, segStart, nTargets, sliceStart, keys, overflowCount);
+    return hipGetLastError();
+}
+
+hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
+                            hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ);
+    return hipGetLastError();
+}
+
 hipError_t launchScatterEnds(const int32_t* viewEndI, const int32_t* viewEndJ, const int32_t* ids,
                              int nTargets, int64_t sliceStart, int32_t* outI, int32_t* outJ,
                              hipStream_t stream) {

@@ -302,10 +302,12 @@ def test_errors(capi):
 
 
 @pytest.mark.parametrize("qlen", [53, 24, 64])
-def test_long_groups_beside_the_packed_kernel(capi, qlen):
-    """Variable-length database: the longest groups of a one-strip Smith-Waterman search are
-    computed by the wavefront-per-pair kernel on a side stream, the rest by the lane-per-target
-    kernel - both must agree with the checker, for scores, end locations and full alignments."""
+def test_long_groups_beside_the_packed_kernel(capi, qlen, monkeypatch):
+    """Variable-length database without segmented views: the longest groups of a one-strip
+    Smith-Waterman search are computed by the wavefront-per-pair kernel on a side stream, the
+    rest by the lane-per-target kernel - both must agree with the checker, for scores, end
+    locations and full alignments. (What NW / HW / OV searches of such a database do.)"""
+    monkeypatch.setenv("MIOPAL_NO_SEGMENTS", "1")
     rng = np.random.default_rng(100 + qlen)
     lengths = np.clip(rng.lognormal(5.3, 0.5, size=60_000), 10, 1500).astype(np.int64)
     lengths[rng.integers(0, len(lengths), size=700)] = rng.integers(1500, 3500, size=700)   # long groups
@@ -323,8 +325,7 @@ def test_long_groups_beside_the_packed_kernel(capi, qlen):
     try:
         score = db.search(q, B62, 3, 1, "score", "sw")
         routed = capi.DeviceDatabase.last_routing()
-        # scores only: long targets are searched as overlapping windows inside the packed kernel
-        assert routed[2] > 0 and routed[0] < 128, f"expected a segmented view, got {routed}"
+        assert routed[0] >= 128 and routed[2] > 0, f"expected long groups on the int32 kernel, got {routed}"
         cpu = _cpu_baseline.CpuDatabase(res, off)
         want = cpu.search_sw(q, B62, 3, 1, 8)
         cpu.close()
@@ -383,5 +384,21 @@ def test_segmented_views_every_score(capi, qlen, gaps, matrix):
             assert routed[0] < 64, f"long targets should stay in the packed kernel, got {routed}"
         part = db.search(q, mat, gaps[0], gaps[1], "score", "sw", 1000, 20_000)["score"]
         np.testing.assert_array_equal(part, want[1000:20_000])
+        # end locations and alignments: the windows' first maxima merged by (score, column, row)
+        end = db.search(q, mat, gaps[0], gaps[1], "end", "sw")
+        np.testing.assert_array_equal(end["score"], want)
+        if gaps[1] > 0 and qlen <= 64:
+            assert capi.DeviceDatabase.last_routing()[0] < 64
+        sample = np.unique(np.concatenate([order[-120:], rng.integers(0, len(lengths), size=200)]))
+        sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+        ref = _oracle.search(q, sres, soff, mat, gaps[0], gaps[1], "full" if qlen == 53 else "end", "sw")
+        for key in ("score", "end_q", "end_t"):
+            np.testing.assert_array_equal(end[key][sample], ref[key], err_msg=key)
+        if qlen == 53:
+            full = db.search(q, mat, gaps[0], gaps[1], "full", "sw")
+            for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+                np.testing.assert_array_equal(full[key][sample], ref[key], err_msg=key)
+            for x, k in enumerate(sample):
+                assert full["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
     finally:
         db.close()

@@ -1,0 +1,22 @@
+"""Scratch: SW end / full on log-normal target lengths."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _data, _oracle
+from pyopal_amd import _capi
+from pyopal_amd.matrices import ScoringMatrix
+m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+q = _oracle.encode(_data.README_QUERY)
+rng = np.random.default_rng(7)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
+lengths = np.clip(rng.lognormal(mean=5.55, sigma=0.6, size=n), 20, 8000).astype(np.int64)
+res, off = _data.random_db(rng, lengths)
+db = _capi.DeviceDatabase(res, off, 24)
+for mode in ("score", "end", "full"):
+    for _ in range(3): out = db.search(q, m, 3, 1, mode, "sw")
+    t0 = time.perf_counter()
+    for _ in range(4):
+        out = db.search(q, m, 3, 1, mode, "sw")
+    dt = (time.perf_counter() - t0) / 4
+    print(f"{mode}: {dt*1e3:.3f} ms -> {53*lengths.sum()/dt/1e9:.1f} GCUPS routing {_capi.DeviceDatabase.last_routing()}", file=sys.stderr)
