@@ -1250,112 +1250,112 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
             const int64_t slotDir = (maxWindow + kLanes - 1) * kLanes;
             const int64_t slotOps = (queryLength + maxWindow + 3) & ~(int64_t)3;  // operations of one pair
-            if (n * slotOps > (16ll << 30)) deviceFull = false;  // host-built batches below
-          if (deviceFull) {
-            RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
-            // traceback in batches of whole direction slots
-            // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
-            const int64_t batch =
-                std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
-            void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
-            const bool sortJobs = lanePerPair && maxWindow <= kLongTarget;  // bins live in LDS
-            if (sortJobs) {
-                RC_TRY(ws->get(kSortBins, (size_t)(maxWindow + 1) * sizeof(int), &pbins));
-                RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
-            }
-            RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
-            RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
-            RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
-            const int64_t nBatches = (n + batch - 1) / batch;
-            void *pblock, *ptotals;
-            RC_TRY(ws->get(kOpsOff, (size_t)((batch + 255) / 256) * sizeof(int64_t), &pblock));
-            RC_TRY(ws->get(kOpsTotals, (size_t)(nBatches + 1) * sizeof(int64_t), &ptotals));
-            HIP_TRY(hipMemsetAsync(ptotals, 0, sizeof(int64_t), stream));
-            for (int64_t b0 = 0, b = 0; b0 < n; b0 += batch, ++b) {
-                const int nb = (int)std::min<int64_t>(batch, n - b0);
-                PairJob* jobs = (PairJob*)pjobs + b0;
-                HIP_TRY(launchTraceJobs(nb, packRules(DpRules{1, 1, 0, kLastCell}), (const int32_t*)psq + b0,
-                                        (const int32_t*)pst + b0, (const int32_t*)pi + b0, (const int32_t*)pj + b0,
-                                        db->d_offsets + start + b0, slotDir, jobs, stream));
-                // job.out is relative to the batch: offset the score pointer
-                WalkArgs wa{};
-                if (lanePerPair) {
-                    // neighbours of similar length share a wavefront; results stay addressed by job.out
-                    if (sortJobs) {
-                        HIP_TRY(launchSortJobsByLength(jobs, nb, (int)maxWindow, (int*)pbins, (PairJob*)psorted,
-                                                       stream));
-                        jobs = (PairJob*)psorted;
-                        wa.slotByOut = 1;
+            const bool fits = n * slotOps <= (16ll << 30);  // else: host-built batches below
+            if (fits) {
+                RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
+                // traceback in batches of whole direction slots
+                // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
+                const int64_t batch =
+                    std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
+                void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
+                const bool sortJobs = lanePerPair && maxWindow <= kLongTarget;  // bins live in LDS
+                if (sortJobs) {
+                    RC_TRY(ws->get(kSortBins, (size_t)(maxWindow + 1) * sizeof(int), &pbins));
+                    RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
+                }
+                RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
+                RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
+                RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
+                const int64_t nBatches = (n + batch - 1) / batch;
+                void *pblock, *ptotals;
+                RC_TRY(ws->get(kOpsOff, (size_t)((batch + 255) / 256) * sizeof(int64_t), &pblock));
+                RC_TRY(ws->get(kOpsTotals, (size_t)(nBatches + 1) * sizeof(int64_t), &ptotals));
+                HIP_TRY(hipMemsetAsync(ptotals, 0, sizeof(int64_t), stream));
+                for (int64_t b0 = 0, b = 0; b0 < n; b0 += batch, ++b) {
+                    const int nb = (int)std::min<int64_t>(batch, n - b0);
+                    PairJob* jobs = (PairJob*)pjobs + b0;
+                    HIP_TRY(launchTraceJobs(nb, packRules(DpRules{1, 1, 0, kLastCell}), (const int32_t*)psq + b0,
+                                            (const int32_t*)pst + b0, (const int32_t*)pi + b0, (const int32_t*)pj + b0,
+                                            db->d_offsets + start + b0, slotDir, jobs, stream));
+                    // job.out is relative to the batch: offset the score pointer
+                    WalkArgs wa{};
+                    if (lanePerPair) {
+                        // neighbours of similar length share a wavefront; results stay addressed by job.out
+                        if (sortJobs) {
+                            HIP_TRY(launchSortJobsByLength(jobs, nb, (int)maxWindow, (int*)pbins, (PairJob*)psorted,
+                                                           stream));
+                            jobs = (PairJob*)psorted;
+                            wa.slotByOut = 1;
+                        }
+                        PerPairArgs pa = perPair;
+                        pa.jobs = jobs;
+                        pa.nJobs = nb;
+                        pa.dirs = (uint8_t*)pd;
+                        pa.score = (int32_t*)pts + b0;  // job.out is relative to the batch
+                        pa.dirWaveStride = slotDir * kLanes;
+                        HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
+                        wa.dirWaveStride = pa.dirWaveStride;
+                    } else {
+                        RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
                     }
-                    PerPairArgs pa = perPair;
-                    pa.jobs = jobs;
-                    pa.nJobs = nb;
-                    pa.dirs = (uint8_t*)pd;
-                    pa.score = (int32_t*)pts + b0;  // job.out is relative to the batch
-                    pa.dirWaveStride = slotDir * kLanes;
-                    HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
-                    wa.dirWaveStride = pa.dirWaveStride;
-                } else {
-                    RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
+                    wa.jobs = jobs;
+                    wa.nJobs = nb;
+                    wa.residues = db->d_residues;
+                    wa.query = s.d_query;
+                    wa.dirs = (const uint8_t*)pd;
+                    wa.ops = (uint8_t*)pslots;
+                    wa.opsOff = nullptr;
+                    wa.opsSlot = slotOps;
+                    wa.queryLength = queryLength;
+                    wa.opsLen = (int32_t*)plen + b0;
+                    HIP_TRY(launchWalk(wa, stream));
+                    HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
+                                            (int64_t*)pblock, (const int64_t*)ptotals + b, (int64_t*)ptotals + b + 1,
+                                            (uint8_t*)pcompact, stream));
                 }
-                wa.jobs = jobs;
-                wa.nJobs = nb;
-                wa.residues = db->d_residues;
-                wa.query = s.d_query;
-                wa.dirs = (const uint8_t*)pd;
-                wa.ops = (uint8_t*)pslots;
-                wa.opsOff = nullptr;
-                wa.opsSlot = slotOps;
-                wa.queryLength = queryLength;
-                wa.opsLen = (int32_t*)plen + b0;
-                HIP_TRY(launchWalk(wa, stream));
-                HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
-                                        (int64_t*)pblock, (const int64_t*)ptotals + b, (int64_t*)ptotals + b + 1,
-                                        (uint8_t*)pcompact, stream));
-            }
-            pt.mark("traceback batches (enqueued)");
-            // results back to the host: the small arrays first (they carry the total size),
-            // the operations while the host turns lengths into offsets
-            int64_t total = 0;
-            // (host scratch kept on the workspace: no malloc / free of megabytes per search)
-            if (ws->hostScratchA.size() < (size_t)n) ws->hostScratchA.resize((size_t)n);
-            if (ws->hostScratchB.size() < (size_t)n) ws->hostScratchB.resize((size_t)n);
-            int32_t* const tscore = ws->hostScratchA.data();
-            int32_t* const lens = ws->hostScratchB.data();
-            RC_TRY(ws->stageDownload(&total, (const int64_t*)ptotals + nBatches, sizeof(int64_t)));
-            RC_TRY(ws->stageDownload(lens, plen, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->stageDownload(tscore, pts, (size_t)n * sizeof(int32_t)));
-            RC_TRY(ws->finishDownloads());
-            pt.mark("device pipeline + small D2H");
-            if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
-            if (!outOps->resize((size_t)total)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-            RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
-            outOff[0] = 0;
-            for (int64_t k = 0; k < n; ++k) outOff[k + 1] = outOff[k] + lens[(size_t)k];
-            if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
-            RC_TRY(ws->finishDownloads());
-            pt.mark("operations D2H");
-            for (int64_t k = 0; k < n; ++k)
-                if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k])
-                    return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
-                                tscore[(size_t)k], score[k], (long long)(start + k));
-            if (!flat) {
-                for (int64_t k = 0; k < n; ++k) {
-                    const int64_t len = outOff[k + 1] - outOff[k];
-                    alignment[k] = nullptr;
-                    alignmentLength[k] = (int)len;
-                    if (endQuery[k] < 0 || endTarget[k] < 0) continue;
-                    unsigned char* buf = (unsigned char*)malloc((size_t)std::max<int64_t>(len, 1));
-                    if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-                    memcpy(buf, outOps->data + outOff[k], (size_t)len);
-                    alignment[k] = buf;
+                pt.mark("traceback batches (enqueued)");
+                // results back to the host: the small arrays first (they carry the total size),
+                // the operations while the host turns lengths into offsets
+                int64_t total = 0;
+                // (host scratch kept on the workspace: no malloc / free of megabytes per search)
+                if (ws->hostScratchA.size() < (size_t)n) ws->hostScratchA.resize((size_t)n);
+                if (ws->hostScratchB.size() < (size_t)n) ws->hostScratchB.resize((size_t)n);
+                int32_t* const tscore = ws->hostScratchA.data();
+                int32_t* const lens = ws->hostScratchB.data();
+                RC_TRY(ws->stageDownload(&total, (const int64_t*)ptotals + nBatches, sizeof(int64_t)));
+                RC_TRY(ws->stageDownload(lens, plen, (size_t)n * sizeof(int32_t)));
+                RC_TRY(ws->stageDownload(startQuery, psq, (size_t)n * sizeof(int32_t)));
+                RC_TRY(ws->stageDownload(startTarget, pst, (size_t)n * sizeof(int32_t)));
+                RC_TRY(ws->stageDownload(tscore, pts, (size_t)n * sizeof(int32_t)));
+                RC_TRY(ws->finishDownloads());
+                pt.mark("device pipeline + small D2H");
+                if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
+                if (!outOps->resize((size_t)total)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+                RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
+                outOff[0] = 0;
+                for (int64_t k = 0; k < n; ++k) outOff[k + 1] = outOff[k] + lens[(size_t)k];
+                if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
+                RC_TRY(ws->finishDownloads());
+                pt.mark("operations D2H");
+                for (int64_t k = 0; k < n; ++k)
+                    if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k])
+                        return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
+                                    tscore[(size_t)k], score[k], (long long)(start + k));
+                if (!flat) {
+                    for (int64_t k = 0; k < n; ++k) {
+                        const int64_t len = outOff[k + 1] - outOff[k];
+                        alignment[k] = nullptr;
+                        alignmentLength[k] = (int)len;
+                        if (endQuery[k] < 0 || endTarget[k] < 0) continue;
+                        unsigned char* buf = (unsigned char*)malloc((size_t)std::max<int64_t>(len, 1));
+                        if (!buf) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+                        memcpy(buf, outOps->data + outOff[k], (size_t)len);
+                        alignment[k] = buf;
+                    }
                 }
+                pt.mark("host copy-out");
+                return 0;
             }
-            pt.mark("host copy-out");
-            return 0;
-          }
         }
     }
 
