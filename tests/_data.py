@@ -14,6 +14,11 @@ README_TARGETS = [  # README.md:87-92
 ]
 
 
+def encode(seq):
+    """Letters -> ordinals over the NCBI alphabet order (pure Python; no checker involved)."""
+    return np.array([NCBI.index(c) for c in seq], dtype=np.uint8)
+
+
 def random_protein(rng, length):
     return AA20_CODES[rng.integers(0, 20, size=length)]
 

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-import _data, _oracle
+import _data
 from pyopal_amd import _capi
 from pyopal_amd.matrices import ScoringMatrix
 
@@ -14,7 +14,7 @@ Q = int(sys.argv[3]) if len(sys.argv) > 3 else 53
 algo = sys.argv[4] if len(sys.argv) > 4 else "sw"
 rng = np.random.default_rng(1)
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
-q = _oracle.encode(_data.README_QUERY) if Q == 53 else _data.random_protein(rng, Q)
+q = _data.encode(_data.README_QUERY) if Q == 53 else _data.random_protein(rng, Q)
 res, off = _data.random_db(rng, np.full(N, L))
 t0 = time.time(); db = _capi.DeviceDatabase(res, off, 24); t1 = time.time()
 out = torch.zeros(N, dtype=torch.int32, device="cuda:0")
@@ -31,7 +31,4 @@ for it in range(3):
     n, ms = db.last_kernel_time()
     cells = Q * N * L
     print(f"wall {dt*1e3:.3f} ms/search -> {cells/dt/1e9:.1f} GCUPS; kernel {ms/max(n,1):.3f} ms x{n} -> {cells/(ms/max(n,1)*1e-3)/1e9:.1f} GCUPS")
-sub = slice(0, 2000)
-ref = _oracle.search(q, res[:off[2000]], off[:2001], m, 3, 1, "score", algo)
-assert np.array_equal(out.cpu().numpy()[sub], ref["score"]), "mismatch vs oracle"
-print("checksum", int(out.sum().item()), "first 2000 match oracle")
+print("checksum", int(out.sum().item()))

@@ -3,11 +3,11 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import _data, _oracle
+import _data
 from pyopal_amd import _capi
 from pyopal_amd.matrices import ScoringMatrix
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
-q = _oracle.encode(_data.README_QUERY)
+q = _data.encode(_data.README_QUERY)
 rng = np.random.default_rng(1)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 res, off = _data.random_db(rng, np.full(N, 300))
@@ -18,8 +18,3 @@ for mode in ("score", "end", "full"):
         t = time.perf_counter(); out = db.search(q, m, 3, 1, mode, "sw"); dt = time.perf_counter() - t
         nk, ms = db.last_kernel_time()
         if rep: print(f"{mode} #{rep}: {dt*1e3:.2f} ms (dominant kernel {ms:.2f} ms)", file=sys.stderr)
-ref = _oracle.search(q, res[:off[2000]], off[:2001], m, 3, 1, "end", "sw")
-end = db.search(q, m, 3, 1, "end", "sw")
-for k in ("score", "end_q", "end_t"):
-    assert np.array_equal(end[k][:2000], ref[k]), k
-print("end sample matches the checker", file=sys.stderr)

@@ -3,11 +3,11 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import _data, _oracle
+import _data
 from pyopal_amd import _capi
 from pyopal_amd.matrices import ScoringMatrix
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
-q = _oracle.encode(_data.README_QUERY)
+q = _data.encode(_data.README_QUERY)
 rng = np.random.default_rng(7)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500_000
 lengths = np.clip(rng.lognormal(mean=5.55, sigma=0.6, size=n), 20, 8000).astype(np.int64)

@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-import _data, _oracle
+import _data
 from pyopal_amd import _capi
 from pyopal_amd.matrices import ScoringMatrix
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
