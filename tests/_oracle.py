@@ -10,7 +10,7 @@ _LIB = None
 
 SEARCH = {"score": 0, "end": 1, "full": 2}
 MODE = {"nw": 0, "hw": 1, "ov": 2, "sw": 3}
-NCBI = "ARNDCQEGHILKMFPSTWYVBZX*"
+from _data import NCBI  # noqa: E402
 
 
 def lib():
