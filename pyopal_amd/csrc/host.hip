@@ -736,8 +736,9 @@ struct Search {
         if (mode == OPAL_MODE_SW && std::min(open, ext) > 0 && maxScore > 0 && (int64_t)Q * maxScore < (1 << 23) &&
             Q < 65536 && db->maxLen < (1 << 24) && !getenv("MIOPAL_NO_SEGMENTS")) {
             const int64_t reach = Q + (int64_t)Q * maxScore / std::min(open, ext) + 1;
-            // (steps of 256: queries of similar length share one cached view)
-            const int64_t rounded = (reach + 255) / 256 * 256;
+            // (steps of 128: queries of similar length share one cached view, and the window - the
+            // critical path of a group of long targets - stays close to what the query needs)
+            const int64_t rounded = (reach + 127) / 128 * 128;
             if (rounded <= 2048 && db->maxLen > segmentStride((int)rounded) + rounded) overlap = (int)rounded;
         }
         std::shared_ptr<View> view;
