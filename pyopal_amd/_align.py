@@ -10,13 +10,11 @@ collective is involved.
 from __future__ import annotations
 
 import contextlib
-import functools
 import multiprocessing.pool
 import typing
 
 from . import _capi
-from .lib import Aligner, BaseDatabase, Database, ScoreResult
-from .matrices import ScoringMatrix
+from .lib import Aligner, BaseDatabase, Database, ScoreResult, resolve_scoring_matrix
 
 
 def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend: int = 1,
@@ -29,42 +27,30 @@ def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend
     CPU core, ``src/pyopal/_align.py:117-118``); any other value is honoured as
     the number of chunks, as in the reference.
     """
-    if scoring_matrix is None:
-        scoring_matrix = Aligner._DEFAULT_SCORING_MATRIX
-    elif isinstance(scoring_matrix, str):
-        scoring_matrix = ScoringMatrix.from_name(scoring_matrix)
-    elif not isinstance(scoring_matrix, ScoringMatrix):
-        ty = type(scoring_matrix).__name__
-        raise TypeError(f"expected str or ScoringMatrix, got {ty}")
-    if not isinstance(database, BaseDatabase):
-        database = Database(database, scoring_matrix.alphabet)
+    matrix = resolve_scoring_matrix(scoring_matrix, "got")
+    targets = database if isinstance(database, BaseDatabase) else Database(database, matrix.alphabet)
+    size = len(targets)
+    aligner = Aligner(matrix, gap_open=gap_open, gap_extend=gap_extend)
+    options = dict(mode=mode, overflow=overflow, algorithm=algorithm)
 
     devices = max(1, _capi.lib().miopalDeviceCount())
-    if threads == 0:
-        threads = devices
-    if threads > len(database):
-        threads = len(database) or 1
-
-    aligner = Aligner(scoring_matrix, gap_open=gap_open, gap_extend=gap_extend)
-    if threads == 1:
-        yield from aligner.align(query, database, mode=mode, overflow=overflow, algorithm=algorithm)
+    chunks = min(threads or devices, size or 1)
+    if chunks == 1:
+        # one search on the calling thread
+        yield from aligner.align(query, targets, **options)
         return
 
-    pool_context: typing.ContextManager
-    if pool is None:
-        pool_context = multiprocessing.pool.ThreadPool(threads)
-    else:
-        pool_context = contextlib.nullcontext(pool)
-    chunk_length = len(database) // threads
-    starts = range(0, len(database), chunk_length)
-    with pool_context as workers:
-        search = functools.partial(aligner.align, query, database, mode=mode, overflow=overflow,
-                                   algorithm=algorithm)
+    # contiguous chunks of size // chunks targets (the remainder makes one more, short chunk,
+    # as in the reference), chunk k on GPU k mod devices
+    step = size // chunks
+    jobs = [(begin, begin + step, k % devices) for k, begin in enumerate(range(0, size, step))]
 
-        def run(item):
-            k, x = item
-            return search(start=x, end=x + chunk_length, device=k % devices)
+    def search(job):
+        begin, stop, device = job
+        return aligner.align(query, targets, start=begin, end=stop, device=device, **options)
 
-        mapper = workers.imap if ordered else workers.imap_unordered
-        for hits in mapper(run, enumerate(starts)):
+    with contextlib.ExitStack() as stack:
+        workers = pool if pool is not None else stack.enter_context(multiprocessing.pool.ThreadPool(chunks))
+        results = workers.imap(search, jobs) if ordered else workers.imap_unordered(search, jobs)
+        for hits in results:
             yield from hits

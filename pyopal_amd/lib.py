@@ -472,6 +472,19 @@ _RESULT_TYPES = {"score": ScoreResult, "end": EndResult, "full": FullResult}
 
 # --- Aligner ------------------------------------------------------------------------
 
+def resolve_scoring_matrix(spec, verb: str = "found") -> ScoringMatrix:
+    """``None`` (BLOSUM50), a matrix name or a `ScoringMatrix`: what `Aligner`
+    (``src/pyopal/lib.pyx:1202-1212``) and `pyopal.align` (``src/pyopal/_align.py:119-127``)
+    accept; their error messages differ by one word."""
+    if isinstance(spec, ScoringMatrix):
+        return spec
+    if spec is None:
+        return Aligner._DEFAULT_SCORING_MATRIX
+    if isinstance(spec, str):
+        return ScoringMatrix.from_name(spec)
+    raise TypeError(f"expected str or ScoringMatrix, {verb} {type(spec).__name__}")
+
+
 class Aligner:
     """The Opal aligner, served by MI355X kernels
     (``src/pyopal/lib.pyx:1122-1383``)."""
@@ -482,15 +495,7 @@ class Aligner:
 
     def __init__(self, scoring_matrix=None, gap_open: int = _DEFAULT_GAP_OPEN,
                  gap_extend: int = _DEFAULT_GAP_EXTEND):
-        if scoring_matrix is None:
-            self.scoring_matrix = self._DEFAULT_SCORING_MATRIX
-        elif isinstance(scoring_matrix, str):
-            self.scoring_matrix = ScoringMatrix.from_name(scoring_matrix)
-        elif isinstance(scoring_matrix, ScoringMatrix):
-            self.scoring_matrix = scoring_matrix
-        else:
-            ty = type(scoring_matrix).__name__
-            raise TypeError(f"expected str or ScoringMatrix, found {ty}")
+        self.scoring_matrix = resolve_scoring_matrix(scoring_matrix, "found")
         self.alphabet = Alphabet(self.scoring_matrix.alphabet)
         self.gap_open = int(gap_open)
         self.gap_extend = int(gap_extend)
