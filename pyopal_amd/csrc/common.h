@@ -161,8 +161,8 @@ hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* s
                             const int32_t* endT, const int32_t* rScore, const int32_t* rI, const int32_t* rJ,
                             int32_t* startQ, int32_t* startT, int* mismatch, hipStream_t stream);
 hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
-                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
-                           hipStream_t stream);
+                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, int64_t wsStride,
+                           PairJob* jobs, hipStream_t stream);
 // Counting sort by tLen, longest first (maxLen <= kLongTarget: the bins fit LDS). bins: maxLen + 1 ints.
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
                                   hipStream_t stream);
@@ -170,8 +170,9 @@ hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* b
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
                            int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,
                            hipStream_t stream);
-hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
-                             int rules, PairJob* jobs, hipStream_t stream);
+hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT,
+                             const int64_t* offsets, int rules, int64_t wsStride, PairJob* jobs,
+                             hipStream_t stream);
 hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream);
 // segmented views with end locations (pack.hip): keyed atomicMax per window, then unpack
 hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,

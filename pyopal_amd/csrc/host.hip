@@ -668,13 +668,20 @@ struct Search {
         return 0;
     }
 
-    // Same with a job list that already sits in HBM and needs no strip-boundary workspace
-    // (every query piece fits one 64-row strip).
+    // Same with a job list that already sits in HBM. wsStride > 0: the jobs' query pieces may have
+    // more than 64 rows, job k owns wsStride strip-boundary columns at wsOff = k * wsStride.
     int runDeviceJobs(const PairJob* d_jobs, int nJobs, int32_t* d_score, int32_t* d_endI, int32_t* d_endJ,
-                      bool trace = false, uint8_t* d_dirs = nullptr) {
+                      bool trace = false, uint8_t* d_dirs = nullptr, int64_t wsStride = 0) {
         if (nJobs <= 0) return 0;
         RC_TRY(ensurePairInputs());
         IntraseqArgs a{};
+        if (wsStride > 0) {
+            void *b0, *b1;
+            RC_TRY(ws->get(kPairB0, (size_t)nJobs * wsStride * sizeof(int2), &b0));
+            RC_TRY(ws->get(kPairB1, (size_t)nJobs * wsStride * sizeof(int2), &b1));
+            a.boundary[0] = (int2*)b0;
+            a.boundary[1] = (int2*)b1;
+        }
         a.jobs = d_jobs;
         a.nJobs = nJobs;
         a.residues = db->d_residues;
@@ -1186,8 +1193,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     // (start cells, traceback jobs, direction bytes and operations are produced and
     // consumed on the device; the host only prefix-sums the alignment lengths)
     {
-        bool deviceFull = queryLength > 0 && queryLength <= kLanes && db->maxLen > 0 &&
-                          !getenv("MIOPAL_HOST_TRACEBACK");
+        const bool oneStrip = queryLength <= kLanes;
+        bool deviceFull = queryLength > 0 && db->maxLen > 0 && !getenv("MIOPAL_HOST_TRACEBACK");
         if (deviceFull) {
             HostBytes localOps;
             std::vector<int64_t> localOff;
@@ -1200,7 +1207,9 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             }
             void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *pcompact, *pts;
             // one lane per pair (perpair.hip) instead of one wavefront per pair (intraseq.hip)
-            const bool lanePerPair = !getenv("MIOPAL_NO_PERPAIR") && (n > kSmallSearch || getenv("MIOPAL_NO_SMALL_SEARCH"));
+            // (queries of more than one strip: the wavefront-per-pair kernel with strip boundaries)
+            const bool lanePerPair = oneStrip && !getenv("MIOPAL_NO_PERPAIR") &&
+                                     (n > kSmallSearch || getenv("MIOPAL_NO_SMALL_SEARCH"));
             RC_TRY(s.ensurePairInputs());
             PerPairArgs perPair{};
             perPair.residues = db->d_residues;
@@ -1213,18 +1222,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             RC_TRY(ws->get(kStartQ, (size_t)n * sizeof(int32_t), &psq));
             RC_TRY(ws->get(kStartT, (size_t)n * sizeof(int32_t), &pst));
-            RC_TRY(ws->get(kMismatch, 2 * sizeof(int), &pmis));
+            RC_TRY(ws->get(kMismatch, 3 * sizeof(int), &pmis));
             RC_TRY(ws->get(kOpsLen, (size_t)n * sizeof(int32_t), &plen));
             RC_TRY(ws->get(kRScore, (size_t)n * sizeof(int32_t), &rs));
-            HIP_TRY(hipMemsetAsync(pmis, 0, 2 * sizeof(int), stream));
+            HIP_TRY(hipMemsetAsync(pmis, 0, 3 * sizeof(int), stream));
             if (mode != OPAL_MODE_NW) {
                 RC_TRY(ws->get(kRI, (size_t)n * sizeof(int32_t), &ri));
                 RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
                 const DpRules rr{1, 1, 0, fr.region};
-                HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
-                                          db->d_offsets + start,
-                                          packRules(rr), (PairJob*)pjobs, stream));
                 if (lanePerPair) {
+                    HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
+                                              db->d_offsets + start, packRules(rr), 0, (PairJob*)pjobs, stream));
                     PerPairArgs pa = perPair;
                     pa.jobs = (const PairJob*)pjobs;
                     pa.nJobs = (int)n;
@@ -1233,7 +1241,18 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     pa.endJ = (int32_t*)rj;
                     HIP_TRY(launchPerPair(pa, fr.region, stream));
                 } else {
-                    RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
+                    // chunks of targets whose strip boundaries (16 B per column and pair) fit 4 GB
+                    const int64_t wsStride = oneStrip ? 0 : db->maxLen;
+                    const int64_t chunk = oneStrip ? n : std::max<int64_t>(1, (4ll << 30) / (16 * wsStride));
+                    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                        const int nc = (int)std::min<int64_t>(chunk, n - c0);
+                        PairJob* jobs = (PairJob*)pjobs + c0;
+                        HIP_TRY(launchReverseJobs(nc, (const int32_t*)ps + c0, (const int32_t*)pi + c0,
+                                                  (const int32_t*)pj + c0, db->d_offsets + start + c0,
+                                                  packRules(rr), wsStride, jobs, stream));
+                        RC_TRY(s.runDeviceJobs(jobs, nc, (int32_t*)rs + c0, (int32_t*)ri + c0, (int32_t*)rj + c0,
+                                               false, nullptr, wsStride));
+                    }
                 }
             }
             HIP_TRY(launchStartCells((int)n, mode, gapOpen, gapExt, (const int32_t*)ps, (const int32_t*)pi,
@@ -1242,15 +1261,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             pt.mark("start cells (enqueued)");
             // The slots of the traceback are sized by the longest target window of the slice
             // (local alignments are short whatever the targets' lengths): one small D2H + sync.
-            int checks[2] = {0, 0};
+            int checks[3] = {0, 0, 0};
             RC_TRY(ws->stageDownload(checks, pmis, sizeof checks));
             RC_TRY(ws->finishDownloads());
             if (checks[0])
                 return fail(MIOPAL_ERR_INTERNAL, "reverse pass disagrees with the forward score for target %lld",
                             (long long)(start + checks[0] - 1));
             const int64_t maxWindow = std::max(checks[1], 1);
-            // direction bytes of one pair (either layout: anti-diagonals of 64 lanes, or 64 rows per column)
-            const int64_t slotDir = (maxWindow + kLanes - 1) * kLanes;
+            const int64_t windowStrips = (std::max(checks[2], 1) + kLanes - 1) / kLanes;  // tallest query window
+            // direction bytes of one pair (either layout: anti-diagonals of 64 lanes per strip, or
+            // 64 rows per column)
+            const int64_t slotDir = windowStrips * (maxWindow + kLanes - 1) * kLanes;
             const int64_t slotOps = (queryLength + maxWindow + 3) & ~(int64_t)3;  // operations of one pair
             const bool fits = n * slotOps <= (16ll << 30);  // else: host-built batches below
             if (fits) {
@@ -1278,7 +1299,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     PairJob* jobs = (PairJob*)pjobs + b0;
                     HIP_TRY(launchTraceJobs(nb, packRules(DpRules{1, 1, 0, kLastCell}), (const int32_t*)psq + b0,
                                             (const int32_t*)pst + b0, (const int32_t*)pi + b0, (const int32_t*)pj + b0,
-                                            db->d_offsets + start + b0, slotDir, jobs, stream));
+                                            db->d_offsets + start + b0, slotDir, windowStrips > 1 ? maxWindow : 0, jobs,
+                                            stream));
                     // job.out is relative to the batch: offset the score pointer
                     WalkArgs wa{};
                     if (lanePerPair) {
@@ -1298,7 +1320,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                         HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
                         wa.dirWaveStride = pa.dirWaveStride;
                     } else {
-                        RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd));
+                        RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd,
+                                               windowStrips > 1 ? maxWindow : 0));
                     }
                     wa.jobs = jobs;
                     wa.nJobs = nb;
@@ -1394,8 +1417,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             RC_TRY(ws->get(kJobs, (size_t)n * sizeof(PairJob), &pjobs));
             // pi / pj still hold the end locations of the forward pass (slice order)
             HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
-                                      db->d_offsets + start,
-                                      packRules(rr), (PairJob*)pjobs, stream));
+                                      db->d_offsets + start, packRules(rr), 0, (PairJob*)pjobs, stream));
             RC_TRY(s.runDeviceJobs((const PairJob*)pjobs, (int)n, (int32_t*)rs, (int32_t*)ri, (int32_t*)rj));
         } else {
             std::vector<PairJob> jobs(live.size());

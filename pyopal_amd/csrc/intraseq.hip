@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
 // reversed prefixes q[0..endQ], t[0..endT] anchored on the end cell. Targets without an
 // end cell get an empty job (its outputs are ignored by the host).
 __global__ void reverse_jobs_kernel(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT,
-                                    const int64_t* offsets, int rules, PairJob* jobs) {
+                                    const int64_t* offsets, int rules, int64_t wsStride, PairJob* jobs) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const int qe = endQ[k], te = endT[k];
@@ -297,6 +297,7 @@ __global__ void reverse_jobs_kernel(int n, const int32_t* score, const int32_t* 
     j.rules = rules;
     j.tStep = -1;
     j.qStep = -1;
+    j.wsOff = (int64_t)k * wsStride;  // strip-boundary workspace (queries of more than 64 rows)
     if (score) {
         // the reversed problem has the same optimum as the forward one: stop at its first column
         j.rules |= kRuleStop;
@@ -319,10 +320,11 @@ __global__ void start_cells_kernel(int n, int mode, int open, int ext, const int
                                    const int32_t* endQ, const int32_t* endT, const int32_t* rScore,
                                    const int32_t* rI, const int32_t* rJ, int32_t* startQ,
                                    int32_t* startT, int* mismatch) {
-    // mismatch[0]: 1 + index of a slot whose reverse pass disagrees; mismatch[1]: longest target
-    // window of the slice (sizes the direction and operation slots of the traceback)
+    // mismatch[0]: 1 + index of a slot whose reverse pass disagrees; mismatch[1], [2]: longest
+    // target window and tallest query window of the slice (they size the direction and
+    // operation slots of the traceback)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    int window = 0;
+    int window = 0, rows = 0;
     const bool live = k < n;
     const int qe = live ? endQ[k] : -1, te = live ? endT[k] : -1;
     int sq = -1, st = -1;
@@ -349,20 +351,25 @@ __global__ void start_cells_kernel(int n, int mode, int open, int ext, const int
             st = te - rj;
         }
         window = te - st + 1;
+        rows = qe - sq + 1;
     }
     if (live) {
         startQ[k] = sq;
         startT[k] = st;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) window = max(window, __shfl_xor(window, off));
+    for (int off = 32; off > 0; off >>= 1) {
+        window = max(window, __shfl_xor(window, off));
+        rows = max(rows, __shfl_xor(rows, off));
+    }
     if ((threadIdx.x & 63) == 0 && window > 0) atomicMax(&mismatch[1], window);
+    if ((threadIdx.x & 63) == 0 && rows > 0) atomicMax(&mismatch[2], rows);
 }
 
 // Traceback jobs on the [start..end] rectangles; job k owns direction slot k.
 __global__ void trace_jobs_kernel(int n, int rules, const int32_t* startQ, const int32_t* startT,
                                   const int32_t* endQ, const int32_t* endT, const int64_t* offsets,
-                                  int64_t dirStride, PairJob* jobs) {
+                                  int64_t dirStride, int64_t wsStride, PairJob* jobs) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     PairJob j{};
@@ -371,6 +378,7 @@ __global__ void trace_jobs_kernel(int n, int rules, const int32_t* startQ, const
     j.tStep = 1;
     j.qStep = 1;
     j.dirOff = (int64_t)k * dirStride;
+    j.wsOff = (int64_t)k * wsStride;  // strip-boundary workspace (windows of more than 64 rows)
     if (endQ[k] >= 0 && endT[k] >= 0) {
         j.tOff = offsets[k] + startT[k];
         j.tLen = endT[k] - startT[k] + 1;
@@ -527,11 +535,11 @@ hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* s
 }
 
 hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
-                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, PairJob* jobs,
-                           hipStream_t stream) {
+                           const int32_t* endT, const int64_t* offsets, int64_t dirStride, int64_t wsStride,
+                           PairJob* jobs, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(trace_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, rules, startQ, startT,
-                       endQ, endT, offsets, dirStride, jobs);
+                       endQ, endT, offsets, dirStride, wsStride, jobs);
     return hipGetLastError();
 }
 
@@ -547,10 +555,11 @@ hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const
 }
 
 hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, const int32_t* endT,
-                             const int64_t* offsets, int rules, PairJob* jobs, hipStream_t stream) {
+                             const int64_t* offsets, int rules, int64_t wsStride, PairJob* jobs,
+                             hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(reverse_jobs_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, score, endQ, endT,
-                       offsets, rules, jobs);
+                       offsets, rules, wsStride, jobs);
     return hipGetLastError();
 }
 
