@@ -132,6 +132,23 @@ def test_alternative_kernel_variants(capi, monkeypatch, switch):
                 compare(gpu, ref, mode, f"{switch} {algo}/{mode} Q={qlen}")
 
 
+@pytest.mark.parametrize("switch", ["MIOPAL_HOST_TRACEBACK", "MIOPAL_NO_PERPAIR", "MIOPAL_NO_SIDE_STREAM"])
+def test_alternative_full_mode_paths(capi, monkeypatch, switch):
+    # fallbacks of `full`: traceback batches built on the host, wavefront-per-pair kernels for
+    # one-strip queries, long targets recomputed after (not beside) the packed kernel
+    monkeypatch.setenv(switch, "1")
+    monkeypatch.setenv("MIOPAL_NO_SEGMENTS", "1")
+    rng = np.random.default_rng(23)
+    lengths = rng.integers(1, 400, size=5000)
+    lengths[:40] = rng.integers(2000, 9000, size=40)
+    res, off = _data.random_db(rng, lengths)
+    for qlen in (53, 130):
+        q = _data.random_protein(rng, qlen)
+        for algo in ALGOS:
+            gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "full", algo)
+            compare(gpu, ref, "full", f"{switch} {algo} Q={qlen}")
+
+
 @pytest.mark.parametrize("qlen", [1, 7, 8, 9, 53, 63, 64, 65, 100, 128, 129, 200, 333])
 def test_query_lengths_sw_score(capi, qlen):
     # strip boundaries of the inter-sequence kernel (8-row blocks, 64-row strips)
