@@ -35,7 +35,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
         smat[(idx / A) * kMatStride + (idx % A)] = a.matrix[idx];
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6;
+    // (readfirstlane tells the compiler what it cannot see: the wavefront index, and with it the
+    // job and every loop bound derived from it, is uniform - scalar loads, scalar loop control)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int jobIdx = blockIdx.x * kJobsPerBlock + wave;
     if (jobIdx >= a.nJobs) return;  // wave-uniform, after the only barrier
@@ -64,10 +66,14 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             const bool rowActive = i < Q;
             const int qres = rowActive ? qptr[(int64_t)i * job.qStep] : 0;
             const int* srow = smat + qres * kMatStride;
+            // Lane state. hLeft = H[i][j-1] doubles as the value handed to the row below (it is read
+            // by wave_shr before this step overwrites it, i.e. as H[i][j-1] = H of the row above at
+            // the reader's column); before a lane starts it holds the left border H[i][-1], which
+            // is exactly the diagonal / upper value the row below needs for its first column.
             int hLeft = leftGap ? borderGap(i, open, ext) : 0;  // H[i][-1]
             int eLeft = kNegInf;
             int hDiag = (i == 0) ? 0 : (leftGap ? borderGap(i - 1, open, ext) : 0);  // H[i-1][-1]
-            int hCur = 0, fCur = kNegInf;
+            int fCur = kNegInf;
             const int2* bin = a.boundary[(s + 1) & 1] + job.wsOff;
             int2* bout = a.boundary[s & 1] + job.wsOff;
             const bool lastStrip = s + 1 == nStrips;
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
 
             // per-lane candidate rules, hoisted out of the step loop
             const bool rowIsLast = i == Q - 1;
-            const bool candAlways = region == kAllCells || (rowIsLast && region != kLastCell);
-            const bool candOnLastCol = region == kLastRowCol || (region == kLastCell && rowIsLast);
+            const bool candAlways = rowActive && (region == kAllCells || (rowIsLast && region != kLastCell));
+            const bool candOnLastCol = rowActive && (region == kLastRowCol || (region == kLastCell && rowIsLast));
             const bool writer = lane == kLanes - 1 && !lastStrip;
 
             // A step is a chain of dependent operations (a pair is L + 63 steps long, however
@@ -87,11 +93,15 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
             //    while step k is computed;
             //  * the values entering lane 0 (next residue, row above the strip) sit in 64-entry
             //    lane buffers that are rotated by one lane per step (wave_rol:1); wave_shr:1
-            //    keeps its `old` operand in lane 0, so feeding lane 0 costs no select.
+            //    keeps its `old` operand in lane 0, so feeding lane 0 costs no select;
+            //  * the top border of the first strip is kept as two running sums (one gap of k + 1
+            //    residues, k + 1 one-residue gaps: common.h borderGap) instead of being
+            //    multiplied out at every step.
             constexpr int kShr1 = 0x138, kRol1 = 0x134;
             int tres = lane == 0 ? (int)tptr[0] : 0;  // residue of step 0 (lane 0 only)
             int scCur = srow[tres];
             int tbuf = 0, bH = 0, bF = kNegInf;
+            int topOne = open, topMany = open;  // cost of the border cell of step k, either way
 
             // the last strip has min(Q - 64 s, 64) rows: its sweep is that much shorter
             const int rows = min(Q - s * kLanes, kLanes);
@@ -118,16 +128,17 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     // DP stage of step k
                     int hTop = bH, fTop = bF;
                     if (s == 0) {
-                        hTop = topGap ? borderGap(k, open, ext) : 0;
+                        hTop = topGap ? -min(topOne, topMany) : 0;
                         fTop = kNegInf;
+                        topOne += ext;
+                        topMany += open;
                     } else {
                         bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
                         bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
                     }
-                    const int hUp = __builtin_amdgcn_update_dpp(hTop, hCur, kShr1, 0xf, 0xf, false);
+                    const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
                     const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
                     const int j = k - lane;
-                    const bool valid = rowActive && (unsigned)j < (unsigned)L;
                     const int eOpen = hLeft - open, eExt = eLeft - ext;
                     const int fOpen = hUp - open, fExt = fUp - ext;
                     const int e = max(eOpen, eExt);
@@ -138,22 +149,27 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     if (TRACE) {
                         // priority diag > E (target gap) > F (query gap); inside a gap,
                         // closing it (back to H) is preferred to extending it
-                        uint8_t code = (h == d) ? 0 : (h == e) ? 1 : 2;
-                        if (e == eOpen) code |= 4;
-                        if (f == fOpen) code |= 8;
-                        dirs[(size_t)k * kLanes + lane] = code;
+                        const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
+                        dirs[(size_t)k * kLanes + lane] =
+                            (uint8_t)(which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0));
                     }
-                    hDiag = valid ? hUp : hDiag;
-                    hLeft = valid ? h : hLeft;
-                    eLeft = valid ? e : eLeft;
-                    hCur = valid ? h : hCur;
-                    fCur = valid ? f : fCur;
-                    const bool cand = candAlways || (candOnLastCol && j == L - 1);
-                    const bool take = valid && cand && (h > best || (h == best && j < bj));
+                    // a lane that has not reached its first column keeps its borders; past its
+                    // last column nothing reads its state any more
+                    const bool started = j >= 0;
+                    hDiag = hUp;
+                    hLeft = started ? h : hLeft;
+                    eLeft = started ? e : eLeft;
+                    fCur = started ? f : fCur;
+                    // candidates: inside a strip a lane's columns come in order, but the lane's row
+                    // of a later strip may tie with an earlier strip's best at a smaller column;
+                    // ties between lanes are settled at the end
+                    const bool inside = (unsigned)j < (unsigned)L;
+                    const bool take = inside && (candAlways || (candOnLastCol && j == L - 1)) &&
+                                      (h > best || (h == best && j < bj));
                     best = take ? h : best;
                     bi = take ? i : bi;
                     bj = take ? j : bj;
-                    if (writer && valid) bout[j] = make_int2(h, f);
+                    if (writer && inside) bout[j] = make_int2(h, f);
                     scCur = scNext;
                     if (stopEnabled) {
                         // First maximum of the column-major scan = the first column holding the
