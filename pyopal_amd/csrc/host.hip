@@ -770,9 +770,46 @@ struct Search {
             if (list.empty() || list.back().out != (int32_t)(id - start)) list.push_back(forwardJob(id, rules));
         };
 
-        const int nStrips = std::max(1, (Q + kMaxStripRows - 1) / kMaxStripRows);
-        // strips of a group in flight (wavefronts per workgroup)
-        const int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
+        // Strips and wavefronts per workgroup for queries of more than 64 rows. A workgroup of W
+        // wavefronts pipelines W strips of one group; a round with fewer strips than W leaves
+        // wavefronts (and their registers and LDS) idle, so the number of strips is a multiple
+        // of W, at the price of shorter strips (each strip pays ~6 rows' worth of per-column
+        // overhead). Measured on 500k x 300 (tools history): Q=300 as 5 strips / 4 wavefronts
+        // 10.1 ms, as 8 / 4 6.6 ms; Q=150 as 3 / 2 4.7 ms, as 4 / 4 3.3 ms. W = 4 is the cheapest
+        // pipeline per cell, W = 8 pays off when there are too few groups to fill the chip
+        // (Q=2000 vs 100k x 2000: 782 groups), W = 1 (strips in turn through HBM) only with
+        // thousands of groups.
+        int nStrips = std::max(1, (Q + kMaxStripRows - 1) / kMaxStripRows);
+        int waves = nStrips >= 8 ? 8 : nStrips >= 4 ? 4 : nStrips >= 2 ? 2 : 1;
+        if (Q > kMaxStripRows) {
+            const double need = 24.0 * db->computeUnits;  // wavefronts that fill the chip
+            const double groups = std::max(1, view->nGroups);
+            double bestCost = 0;
+            for (int w : {4, 8, 2, 1}) {
+                const int strips = w * ((Q + kMaxStripRows * w - 1) / (kMaxStripRows * w));
+                const int rows = ((Q + strips - 1) / strips + 7) / 8 * 8;
+                // (strips are whole multiples of 8 rows; the last one must still hold row Q - 1)
+                if ((strips - 1) * rows >= Q) continue;
+                const double pipeline = w == 4 ? 1.0 : w == 8 ? 1.12 : w == 2 ? 1.06 : 1.08;
+                double cost = (double)strips * (rows + 6) * pipeline;
+                const double parallel = groups * w;
+                if (parallel < need) cost *= need / parallel;
+                if (bestCost == 0 || cost < bestCost) {
+                    bestCost = cost;
+                    nStrips = strips;
+                    waves = w;
+                }
+            }
+        }
+        if (const char* o = getenv("MIOPAL_STRIPS")) {  // experiments: "<strips>,<wavefronts>"
+            int a = 0, b = 0;
+            const int least = std::max(1, (Q + kMaxStripRows - 1) / kMaxStripRows);
+            if (sscanf(o, "%d,%d", &a, &b) == 2 && a >= least && (b == 1 || b == 2 || b == 4 || b == 8) &&
+                (a - 1) * (((Q + a - 1) / a + 7) / 8 * 8) < Q) {
+                nStrips = a;
+                waves = b;
+            }
+        }
         // A group keeps its wavefronts busy for (columns of its longest target) x (rounds of strips).
         // Groups far above the balanced share of a workgroup slot would stretch the kernel to
         // their own length (one lane per target cannot split a target), so the leading

@@ -419,3 +419,20 @@ def test_segmented_views_every_score(capi, qlen, gaps, matrix):
                 assert full["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("config", ["", "4,4", "4,2", "4,1", "8,8", "8,4", "3,1", "6,2", "5,1", "16,8"])
+def test_strip_configurations(capi, monkeypatch, config):
+    """Queries of more than 64 rows: every split into strips and wavefronts that the dispatch
+    may pick (host.hip, cost model; MIOPAL_STRIPS forces one) gives the checker's scores and end
+    locations - including requests that would leave the last strip without a query row, which
+    must be refused rather than run."""
+    if config:
+        monkeypatch.setenv("MIOPAL_STRIPS", config)
+    rng = np.random.default_rng(171)
+    res, off = _data.random_db(rng, rng.integers(1, 500, size=700))
+    for qlen in (65, 100, 150, 200, 333):
+        q = _data.random_protein(rng, qlen)
+        for algo in ALGOS:
+            gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "end", algo)
+            compare(gpu, ref, "end", f"strips {config or 'default'} {algo} Q={qlen}")
