@@ -89,8 +89,9 @@ struct WalkArgs {
     int64_t opsSlot;
     int32_t* opsLen;
     // direction layout: 0 = intraseq_kernel (anti-diagonal major, at job.dirOff),
-    // > 0 = perpair_kernel ([j][i][lane] per 64 consecutive jobs, this many bytes apart)
+    // > 0 = perpair_kernel ([strip][j][i][lane] per 64 consecutive jobs, this many bytes apart)
     int64_t dirWaveStride;
+    int64_t dirStripColumns;  // columns per strip in the perpair_kernel layout
     int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
     int queryLength;          // whole query (staged in LDS when it fits)
 };
@@ -102,15 +103,18 @@ struct PerPairArgs {
     int nJobs;
     const uint8_t* residues;
     const uint8_t* query;
-    int queryLength;          // <= 64
+    int queryLength;          // <= 4096 (staged in LDS)
     const int* matrix;
     int alphabet;
     int gapOpen, gapExt;
     int32_t* score;           // by job.out (trace: score of the last cell of the window)
     int32_t* endI;
     int32_t* endJ;
-    uint8_t* dirs;            // trace: [job / 64][j][i][job % 64]
-    int64_t dirWaveStride;    // bytes per 64 consecutive jobs (>= longest target window * 4096)
+    uint8_t* dirs;            // trace: [job / 64][strip][j][i][job % 64]
+    int64_t dirWaveStride;    // bytes per 64 consecutive jobs (>= strips * dirStripColumns * 4096)
+    int64_t dirStripColumns;  // columns reserved per strip (>= longest target window)
+    int2* boundary;           // query windows of more than 64 rows: [job / 64][column][job % 64]
+    int64_t boundaryStride;   // columns per 64 consecutive jobs (>= longest target window)
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 

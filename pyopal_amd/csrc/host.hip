@@ -1244,8 +1244,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             }
             void *rs = nullptr, *ri = nullptr, *rj = nullptr, *pjobs, *psq, *pst, *pmis, *plen, *pcompact, *pts;
             // one lane per pair (perpair.hip) instead of one wavefront per pair (intraseq.hip)
-            // (queries of more than one strip: the wavefront-per-pair kernel with strip boundaries)
-            const bool lanePerPair = oneStrip && !getenv("MIOPAL_NO_PERPAIR") &&
+            // (it stages the query in LDS: up to 4096 residues; longer ones keep the wavefront-per-pair kernel)
+            const bool lanePerPair = queryLength <= 4096 && !getenv("MIOPAL_NO_PERPAIR") &&
                                      (n > kSmallSearch || getenv("MIOPAL_NO_SMALL_SEARCH"));
             RC_TRY(s.ensurePairInputs());
             PerPairArgs perPair{};
@@ -1268,15 +1268,29 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
                 const DpRules rr{1, 1, 0, fr.region};
                 if (lanePerPair) {
-                    HIP_TRY(launchReverseJobs((int)n, (const int32_t*)ps, (const int32_t*)pi, (const int32_t*)pj,
-                                              db->d_offsets + start, packRules(rr), 0, (PairJob*)pjobs, stream));
-                    PerPairArgs pa = perPair;
-                    pa.jobs = (const PairJob*)pjobs;
-                    pa.nJobs = (int)n;
-                    pa.score = (int32_t*)rs;
-                    pa.endI = (int32_t*)ri;
-                    pa.endJ = (int32_t*)rj;
-                    HIP_TRY(launchPerPair(pa, fr.region, stream));
+                    // chunks of whole wavefronts whose strip boundaries (8 B per column and pair) fit 4 GB
+                    const int64_t chunk =
+                        oneStrip ? n : std::max<int64_t>(kLanes, (4ll << 30) / (8 * db->maxLen) / kLanes * kLanes);
+                    void* pb = nullptr;
+                    if (!oneStrip)
+                        RC_TRY(ws->get(kPairB0, (size_t)((std::min(chunk, n) + kLanes - 1) / kLanes * kLanes) *
+                                                    db->maxLen * sizeof(int2), &pb));
+                    for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+                        const int nc = (int)std::min<int64_t>(chunk, n - c0);
+                        PairJob* jobs = (PairJob*)pjobs + c0;
+                        HIP_TRY(launchReverseJobs(nc, (const int32_t*)ps + c0, (const int32_t*)pi + c0,
+                                                  (const int32_t*)pj + c0, db->d_offsets + start + c0,
+                                                  packRules(rr), 0, jobs, stream));
+                        PerPairArgs pa = perPair;
+                        pa.jobs = jobs;
+                        pa.nJobs = nc;
+                        pa.score = (int32_t*)rs + c0;
+                        pa.endI = (int32_t*)ri + c0;
+                        pa.endJ = (int32_t*)rj + c0;
+                        pa.boundary = (int2*)pb;
+                        pa.boundaryStride = db->maxLen;
+                        HIP_TRY(launchPerPair(pa, fr.region, stream));
+                    }
                 } else {
                     // chunks of targets whose strip boundaries (16 B per column and pair) fit 4 GB
                     const int64_t wsStride = oneStrip ? 0 : db->maxLen;
@@ -1354,8 +1368,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                         pa.dirs = (uint8_t*)pd;
                         pa.score = (int32_t*)pts + b0;  // job.out is relative to the batch
                         pa.dirWaveStride = slotDir * kLanes;
+                        pa.dirStripColumns = maxWindow + kLanes - 1;
+                        if (windowStrips > 1) {
+                            void* pb;
+                            RC_TRY(ws->get(kPairB0, (size_t)((nb + kLanes - 1) / kLanes * kLanes) * maxWindow *
+                                                        sizeof(int2), &pb));
+                            pa.boundary = (int2*)pb;
+                            pa.boundaryStride = maxWindow;
+                        }
                         HIP_TRY(launchPerPair(pa, kPerPairTrace, stream));
                         wa.dirWaveStride = pa.dirWaveStride;
+                        wa.dirStripColumns = pa.dirStripColumns;
                     } else {
                         RC_TRY(s.runDeviceJobs(jobs, nb, (int32_t*)pts + b0, nullptr, nullptr, true, (uint8_t*)pd,
                                                windowStrips > 1 ? maxWindow : 0));

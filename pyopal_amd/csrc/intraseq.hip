@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
             break;
         }
         const int l = i & 63;
-        const uint8_t d = laneMajor ? dirs[((int64_t)j * kLanes + i) * kLanes]
+        const uint8_t d = laneMajor ? dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * kLanes + l) * kLanes]
                                     : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
         if (state == 0) {
             const int c = d & 3;
@@ -378,8 +378,12 @@ __global__ void start_cells_kernel(int n, int mode, int open, int ext, const int
         window = max(window, __shfl_xor(window, off));
         rows = max(rows, __shfl_xor(rows, off));
     }
-    if ((threadIdx.x & 63) == 0 && window > 0) atomicMax(&mismatch[1], window);
-    if ((threadIdx.x & 63) == 0 && rows > 0) atomicMax(&mismatch[2], rows);
+    // (a plain read first: after a few wavefronts the maxima rarely move, and thousands of
+    // atomics on one address would cost more than the rest of the kernel)
+    if ((threadIdx.x & 63) == 0) {
+        if (window > *(volatile int*)&mismatch[1]) atomicMax(&mismatch[1], window);
+        if (rows > *(volatile int*)&mismatch[2]) atomicMax(&mismatch[2], rows);
+    }
 }
 
 // Traceback jobs on the [start..end] rectangles; job k owns direction slot k.

@@ -9,7 +9,9 @@
 // it column by column at 32 bit, like the inter-sequence kernel but with a private query
 // window: H[64] / E[64] of the previous column live in VGPRs, the lane's query residues are
 // pre-scaled LDS row offsets packed two per VGPR, the substitution matrix sits in LDS with an
-// extra pad row and column. A wavefront runs until its longest pair is done.
+// extra pad row and column. A wavefront runs until its longest pair is done. Query windows of
+// more than 64 rows are swept strip by strip; the last row of a strip reaches the next strip
+// through HBM, 512 bytes per wavefront-column.
 //
 // Rows beyond the lane's query window and columns beyond its target read the pad row/column
 // (a large negative score): every value computed there is bounded by a valid cell that comes
@@ -28,17 +30,19 @@ constexpr int kPadScore = -(1 << 28);
 constexpr int kStride = kMaxAlphabet + 1;  // matrix rows in LDS, in ints (pad column included)
 constexpr int kBlock = 256;
 
+constexpr int kQueryLds = 4096;  // longest query the kernel stages in LDS
+
 template <int MODE>  // kAllCells / kLastRow / kLastRowCol: start-location scan; kPerPairTrace: directions
 __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
     __shared__ int smat[kStride * kStride];
-    __shared__ uint8_t qlds[kLanes];
+    __shared__ uint8_t qlds[kQueryLds];
     const int A = a.alphabet;
     for (int idx = threadIdx.x; idx < kStride * kStride; idx += kBlock) {
         const int q = idx / kStride, t = idx % kStride;
         // `open` is folded into the scores: the columns keep H - open (see the cell update)
         smat[idx] = (q < A && t < A) ? a.matrix[q * A + t] + a.gapOpen : kPadScore;
     }
-    if (threadIdx.x < kLanes) qlds[threadIdx.x] = threadIdx.x < a.queryLength ? a.query[threadIdx.x] : 0;
+    for (int x = threadIdx.x; x < a.queryLength; x += kBlock) qlds[x] = a.query[x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -57,94 +61,127 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
     }
     maxQ = __builtin_amdgcn_readfirstlane(maxQ);
     maxL = __builtin_amdgcn_readfirstlane(maxL);
+    const int nStrips = (maxQ + kLanes - 1) / kLanes;  // of the wavefront's tallest window
 
-    // LDS byte offsets of the lane's query rows, two per register; pad row beyond the window
-    uint32_t qo[kLanes / 2];
-#pragma unroll
-    for (int i = 0; i < kLanes; i += 2) {
-        const int q0 = i < Q ? qlds[job.qOff + i * job.qStep] : A;
-        const int q1 = i + 1 < Q ? qlds[job.qOff + (i + 1) * job.qStep] : A;
-        qo[i >> 1] = (uint32_t)(q0 * kStride * 4) | ((uint32_t)(q1 * kStride * 4) << 16);
-    }
-
-    // Previous column, kept as HM = H - open: the same number opens a gap to the right (E of
-    // the next column) and downwards (F of the next row), and the diagonal gets `open` back
-    // from the LDS scores.
-    int HM[kLanes], E[kLanes];
-#pragma unroll
-    for (int i = 0; i < kLanes; ++i) {
-        HM[i] = i < Q ? borderGap(i, open, ext) - open : kNegInf;  // column -1
-        E[i] = kNegInf;
-    }
-
+    // running answer over the strips: (score, column, row) of the first maximum
     int best = INT32_MIN, brow = -1, bcol = -1;
-    const bool stopOn = job.rules & kRuleStop;
+    const bool stopOn = (job.rules & kRuleStop) && nStrips == 1;
     const int stopScore = job.stop;
     const uint8_t* tptr = a.residues + job.tOff;
     const int64_t tStep = job.tStep;
-    uint8_t* dcol = nullptr;
-    if (MODE == kPerPairTrace) dcol = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane;
+    // strip boundaries of the wavefront: (H - open, F) of the strip's last row, per column
+    int2* bnd = a.boundary ? a.boundary + (int64_t)(idx >> 6) * a.boundaryStride * kLanes + lane : nullptr;
+    uint8_t* dirs = nullptr;
+    if (MODE == kPerPairTrace) dirs = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane;
 
-    int tcolNext = (L > 0 ? (int)tptr[0] : A) * 4;
-    for (int j = 0; j < maxL; ++j) {
-        const int tcol = tcolNext;
-        {
-            int t = A;
-            if (j + 1 < L) t = tptr[(int64_t)(j + 1) * tStep];
-            tcolNext = t * 4;
+    for (int s = 0; s < nStrips; ++s) {
+        const int row0 = s * kLanes;
+        const int rowsHere = min(maxQ - row0, kLanes);  // wave-uniform
+        const bool toNext = s + 1 < nStrips;
+        // LDS byte offsets of the lane's query rows, two per register; pad row beyond the window
+        uint32_t qo[kLanes / 2];
+#pragma unroll
+        for (int i = 0; i < kLanes; i += 2) {
+            const int q0 = row0 + i < Q ? qlds[job.qOff + (row0 + i) * job.qStep] : A;
+            const int q1 = row0 + i + 1 < Q ? qlds[job.qOff + (row0 + i + 1) * job.qStep] : A;
+            qo[i >> 1] = (uint32_t)(q0 * kStride * 4) | ((uint32_t)(q1 * kStride * 4) << 16);
         }
-        const char* mcol = (const char*)smat + tcol;
-        int hmUp = borderGap(j, open, ext) - open, fUp = kNegInf;
-        int hmDiag = (j == 0 ? 0 : borderGap(j - 1, open, ext)) - open;
-        const bool colOk = j < L, lastCol = j == L - 1;
-        const int bestBefore = best;
+        // Previous column, kept as HM = H - open: the same number opens a gap to the right (E of
+        // the next column) and downwards (F of the next row), and the diagonal gets `open` back
+        // from the LDS scores.
+        int HM[kLanes], E[kLanes];
 #pragma unroll
         for (int i = 0; i < kLanes; ++i) {
-            if ((i & 7) == 0 && i >= maxQ) break;  // wave-uniform
-            const uint32_t off = (i & 1) ? (qo[i >> 1] >> 16) : (qo[i >> 1] & 0xffffu);
-            const int sc = *(const int*)(mcol + off);
-            const int eOpen = HM[i], eExt = E[i] - ext;
-            const int fOpen = hmUp, fExt = fUp - ext;
-            const int e = max(eOpen, eExt);
-            const int f = max(fOpen, fExt);
-            const int d = hmDiag + sc;
-            const int h = max(d, max(e, f));
-            if (MODE == kPerPairTrace) {
-                // same code as intraseq_kernel<true>: diag > E (target gap) > F (query gap);
-                // inside a gap, closing it is preferred to extending it
-                const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
-                const int code = which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0);
-                dcol[((int64_t)j * kLanes + i) * kLanes] = (uint8_t)code;
-            } else {
-                bool cand = true;  // kAllCells: pad rows / columns never beat a valid cell
-                if (MODE == kLastRow) cand = colOk && i == Q - 1;
-                if (MODE == kLastRowCol) cand = colOk && (i == Q - 1 || (lastCol && i < Q));
-                const bool take = cand && h > best;
-                best = take ? h : best;
-                brow = take ? i : brow;
-            }
-            const int hm = h - open;
-            hmDiag = HM[i];
-            HM[i] = hm;
-            E[i] = e;
-            hmUp = hm;
-            fUp = f;
+            HM[i] = row0 + i < Q ? borderGap(row0 + i, open, ext) - open : kNegInf;  // column -1
+            E[i] = kNegInf;
         }
-        if (MODE == kPerPairTrace) {
-            // score of the window = its last cell; lanes of a wavefront (sorted by length)
-            // finish in a handful of columns, so the row select runs rarely
-            if (__builtin_amdgcn_ballot_w64(lastCol) != 0) {
-                int v = 0;
-#pragma unroll
-                for (int i = 0; i < kLanes; ++i) v = (i == Q - 1) ? HM[i] : v;
-                if (lastCol) best = v + open;
+        // first maximum of this strip (column-major inside the strip)
+        int sbest = INT32_MIN, srow = -1, scol = -1;
+        uint8_t* dcol = MODE == kPerPairTrace ? dirs + (int64_t)s * a.dirStripColumns * (kLanes * kLanes) : nullptr;
+        // row above the strip at column j - 1 (diagonal of the strip's first row)
+        int aboveHmPrev = (s == 0 ? 0 : borderGap(row0 - 1, open, ext)) - open;
+
+        int tcolNext = (L > 0 ? (int)tptr[0] : A) * 4;
+        for (int j = 0; j < maxL; ++j) {
+            const int tcol = tcolNext;
+            {
+                int t = A;
+                if (j + 1 < L) t = tptr[(int64_t)(j + 1) * tStep];
+                tcolNext = t * 4;
             }
-        } else {
-            bcol = best != bestBefore ? j : bcol;  // candidates only ever raise `best`
-            // the optimum of the forward pass is the first maximum of this scan: a lane that
-            // met it is finished; the wavefront leaves when no lane has work left
-            const bool more = j + 1 < L && !(stopOn && best == stopScore);
-            if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+            const char* mcol = (const char*)smat + tcol;
+            int hmUp, fUp;
+            if (s == 0) {
+                hmUp = borderGap(j, open, ext) - open;
+                fUp = kNegInf;
+            } else {
+                const int2 above = bnd[(int64_t)j * kLanes];
+                hmUp = above.x;
+                fUp = above.y;
+            }
+            int hmDiag = aboveHmPrev;
+            aboveHmPrev = hmUp;
+            const bool colOk = j < L, lastCol = j == L - 1;
+            const int bestBefore = sbest;
+#pragma unroll
+            for (int i = 0; i < kLanes; ++i) {
+                if ((i & 7) == 0 && i >= rowsHere) break;  // wave-uniform
+                const uint32_t off = (i & 1) ? (qo[i >> 1] >> 16) : (qo[i >> 1] & 0xffffu);
+                const int sc = *(const int*)(mcol + off);
+                const int eOpen = HM[i], eExt = E[i] - ext;
+                const int fOpen = hmUp, fExt = fUp - ext;
+                const int e = max(eOpen, eExt);
+                const int f = max(fOpen, fExt);
+                const int d = hmDiag + sc;
+                const int h = max(d, max(e, f));
+                if (MODE == kPerPairTrace) {
+                    // same code as intraseq_kernel<true>: diag > E (target gap) > F (query gap);
+                    // inside a gap, closing it is preferred to extending it
+                    const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
+                    const int code = which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0);
+                    dcol[((int64_t)j * kLanes + i) * kLanes] = (uint8_t)code;
+                } else {
+                    bool cand = true;  // kAllCells: pad rows / columns never beat a valid cell
+                    if (MODE == kLastRow) cand = colOk && row0 + i == Q - 1;
+                    if (MODE == kLastRowCol) cand = colOk && (row0 + i == Q - 1 || (lastCol && row0 + i < Q));
+                    const bool take = cand && h > sbest;
+                    sbest = take ? h : sbest;
+                    srow = take ? i : srow;
+                }
+                const int hm = h - open;
+                hmDiag = HM[i];
+                HM[i] = hm;
+                E[i] = e;
+                hmUp = hm;
+                fUp = f;
+            }
+            // (after a full strip hmUp / fUp are those of its last row)
+            if (toNext) bnd[(int64_t)j * kLanes] = make_int2(hmUp, fUp);
+            if (MODE == kPerPairTrace) {
+                // score of the window = its last cell; lanes of a wavefront (sorted by length)
+                // finish in a handful of columns, so the row select runs rarely
+                const bool mine = lastCol && Q > row0 && Q <= row0 + kLanes;  // the lane's last strip
+                if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+                    int v = 0;
+#pragma unroll
+                    for (int i = 0; i < kLanes; ++i) v = (row0 + i == Q - 1) ? HM[i] : v;
+                    if (mine) best = v + open;
+                }
+            } else {
+                scol = sbest != bestBefore ? j : scol;  // candidates only ever raise `sbest`
+                // the optimum of the forward pass is the first maximum of this scan: a lane that
+                // met it is finished; the wavefront leaves when no lane has work left
+                const bool more = j + 1 < L && !(stopOn && sbest == stopScore);
+                if (__builtin_amdgcn_ballot_w64(more) == 0 && !toNext) break;
+            }
+        }
+        if (MODE != kPerPairTrace && Q > row0 && scol >= 0) {
+            // fold the strip in: higher score, then smaller column (rows of later strips are larger)
+            if (sbest > best || (sbest == best && scol < bcol)) {
+                best = sbest;
+                brow = row0 + srow;
+                bcol = scol;
+            }
         }
     }
 
