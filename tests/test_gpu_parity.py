@@ -436,3 +436,35 @@ def test_strip_configurations(capi, monkeypatch, config):
         for algo in ALGOS:
             gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "end", algo)
             compare(gpu, ref, "end", f"strips {config or 'default'} {algo} Q={qlen}")
+
+
+def test_segmented_view_with_lanes_leaving_the_half_float_range(capi):
+    """A window whose lane saturates the first rung (scores >= 2048) is flagged like any other
+    lane, and its target recomputed whole by the next rungs - over the merged window maxima."""
+    rng = np.random.default_rng(5)
+    lengths = np.clip(rng.lognormal(5.3, 0.5, size=20_000), 10, 1500).astype(np.int64)
+    lengths[:30] = rng.integers(4000, 7000, size=30)
+    res, off = _data.random_db(rng, lengths)
+    w = _data.NCBI.index("W")
+    q = np.concatenate([np.full(230, w, dtype=np.uint8), _data.random_protein(rng, 70)])
+    for k in range(0, 30, 3):          # the query itself inside long targets: scores around 2800
+        at = int(rng.integers(100, lengths[k] - 400))
+        res[off[k] + at:off[k] + at + len(q)] = q
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(q, B62, 5, 2, "score", "sw")["score"]
+        routed = capi.DeviceDatabase.last_routing()
+        cpu = _cpu_baseline.CpuDatabase(res, off)
+        want = cpu.search_sw(q, B62, 5, 2, 8)
+        cpu.close()
+        assert want.max() >= 2048 and routed[3] >= 1, (int(want.max()), routed)
+        np.testing.assert_array_equal(got, want)
+        end = db.search(q, B62, 5, 2, "end", "sw")
+        np.testing.assert_array_equal(end["score"], want)
+        sample = np.arange(0, 60)
+        sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+        ref = _oracle.search(q, sres, soff, B62, 5, 2, "end", "sw")
+        for key in ("score", "end_q", "end_t"):
+            np.testing.assert_array_equal(end[key][sample], ref[key], err_msg=key)
+    finally:
+        db.close()
