@@ -75,24 +75,39 @@ def main():
     residues, offsets = _data.random_db(rng, np.full(N, L))
     t0 = time.time()
     db = _capi.DeviceDatabase(residues, offsets, 24, device=local_rank)
-    out = torch.zeros(N, dtype=torch.int32, device=f"cuda:{local_rank}")
+    # two result buffers: the gather of step k runs beside the search of step k + 1
+    outs = [torch.zeros(N, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(2)]
+    out = outs[0]
     stream = torch.cuda.current_stream().cuda_stream
     db.search_device_scores(query, matrix, out.data_ptr(), stream, 3, 1, "sw")  # builds the packed view
     torch.cuda.synchronize()
     build_s = time.time() - t0
     on_device = backend == "nccl"
-    gathered = None
+    gathered = [None, None]
     if world > 1 and rank == 0:
-        gathered = [torch.empty_like(out) if on_device else torch.empty(N, dtype=torch.int32)
-                    for _ in range(world)]
+        gathered = [[torch.empty_like(out) if on_device else torch.empty(N, dtype=torch.int32)
+                     for _ in range(world)] for _ in range(2)]
+    pending = [None, None]
+    counter = [0]
 
     def step():
-        db.search_device_scores(query, matrix, out.data_ptr(), stream, 3, 1, "sw")
+        b = counter[0] & 1
+        counter[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()  # the gather that read this buffer two steps ago (stream-ordered for RCCL)
+            pending[b] = None
+        db.search_device_scores(query, matrix, outs[b].data_ptr(), stream, 3, 1, "sw")
         if world > 1:
-            # the one exchange of the path: per-shard scores to rank 0 (RCCL over xGMI)
-            dist.gather(out if on_device else out.cpu(), gathered, dst=0)
+            # the one exchange of the path: per-shard scores to rank 0 (RCCL over xGMI). Issued
+            # asynchronously: it waits for the search on the current stream, then runs on the
+            # collective's own stream while the next step's search starts.
+            pending[b] = dist.gather(outs[b] if on_device else outs[b].cpu(), gathered[b], dst=0, async_op=True)
 
     def fence():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -106,6 +121,8 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    last = (counter[0] - 1) & 1 if counter[0] else 0   # buffer of the last step
+    out = outs[last]
     n_launch, kernel_ms = db.last_kernel_time()
     db.set_profiling(False)
     if world > 1:
@@ -115,7 +132,7 @@ def main():
         elapsed = float(t.item())
         if rank == 0:
             # the gathered vector of this rank's own shard is what the search wrote
-            assert torch.equal(gathered[0].cpu(), out.cpu())
+            assert torch.equal(gathered[last][0].cpu(), out.cpu())
 
     # (correctness gate: in the cpu_baseline leg below - every score against the AVX2 port,
     # a sample against the scalar checker; the other legs never touch the code under oracle/)
