@@ -96,11 +96,20 @@ static int sw_scalar(const unsigned char* q, int Q, const unsigned char* t, int6
     for (int64_t j = 0; j < L; j++) {
         int diag = 0, f = 0, hup = 0;
         for (int i = 0; i < Q; i++) {
-            int e = E[i] - ext; if (H[i] - open > e) e = H[i] - open; if (e < 0) e = 0;
-            f = f - ext; if (hup - open > f) f = hup - open; if (f < 0) f = 0;
+            int e = E[i] - ext;
+            if (H[i] - open > e) e = H[i] - open;
+            if (e < 0) e = 0;
+            f = f - ext;
+            if (hup - open > f) f = hup - open;
+            if (f < 0) f = 0;
             int h = diag + S[q[i] * A + t[j]];
-            if (e > h) h = e; if (f > h) h = f; if (h < 0) h = 0;
-            diag = H[i]; H[i] = h; E[i] = e; hup = h;
+            if (e > h) h = e;
+            if (f > h) h = f;
+            if (h < 0) h = 0;
+            diag = H[i];
+            H[i] = h;
+            E[i] = e;
+            hup = h;
             if (h > best) best = h;
         }
     }
