@@ -6,6 +6,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
 out_path, needle, kernel_ms = sys.argv[1], sys.argv[2], float(sys.argv[3])
@@ -21,8 +22,10 @@ for d in sys.argv[4:]:
         for k, v in agg.items():
             counters[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
 summary = {
-    "command": "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 5 "
-               "--warmup 1 --no-cpu-baseline (separate passes: SQ+GRBM, FETCH_SIZE, WRITE_SIZE)",
+    "command": os.environ.get(
+        "PMC_COMMAND",
+        "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 5 "
+        "--warmup 1 --no-cpu-baseline (separate passes: SQ+GRBM, FETCH_SIZE, WRITE_SIZE)"),
     "kernel": name,
     "kernel_ms_unprofiled": kernel_ms,
     "counters": counters,
