@@ -258,6 +258,28 @@ struct Workspace {
         *out = buf[slot];
         return 0;
     }
+    // Like get(), but an allocation the device cannot serve is not an error: returns false
+    // (the caller asks for less). The slack of get() is left out: these are the big buffers.
+    bool tryGet(int slot, size_t bytes, void** out) {
+        if (cap[slot] >= bytes) {
+            *out = buf[slot];
+            return true;
+        }
+        if (buf[slot]) {
+            (void)hipStreamSynchronize(stream);
+            (void)hipFree(buf[slot]);
+            buf[slot] = nullptr;
+            cap[slot] = 0;
+        }
+        if (hipMalloc(&buf[slot], bytes) != hipSuccess) {
+            (void)hipGetLastError();  // out of memory is handled by the caller
+            buf[slot] = nullptr;
+            return false;
+        }
+        cap[slot] = bytes;
+        *out = buf[slot];
+        return true;
+    }
     size_t bytes() const {
         size_t t = 0;
         for (size_t c : cap) t += c;
@@ -1327,9 +1349,8 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             const bool fits = n * slotOps <= (16ll << 30);  // else: host-built batches below
             if (fits) {
                 RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
-                // traceback in batches of whole direction slots
-                // (whole wavefronts of 64 pairs: the lane-per-pair layout interleaves their slots)
-                const int64_t batch =
+                // traceback in batches of whole direction slots and whole wavefronts of 64 pairs
+                int64_t batch =
                     std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
                 void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
                 const bool sortJobs = lanePerPair && maxWindow <= kLongTarget;  // bins live in LDS
@@ -1337,7 +1358,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     RC_TRY(ws->get(kSortBins, (size_t)(maxWindow + 1) * sizeof(int), &pbins));
                     RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
                 }
-                RC_TRY(ws->get(kDirs, (size_t)(batch * slotDir), &pd));
+                // the direction workspace is the one allocation that can be refused on a GPU shared
+                // with other work: halve the batch until it fits
+                while (!ws->tryGet(kDirs, (size_t)(batch * slotDir), &pd)) {
+                    if (batch <= kLanes) return fail(MIOPAL_ERR_HIP, "out of device memory for the traceback workspace");
+                    batch = std::max<int64_t>(kLanes, batch / 2 / kLanes * kLanes);
+                }
                 RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
                 RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
                 const int64_t nBatches = (n + batch - 1) / batch;
