@@ -167,7 +167,8 @@ hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* s
 hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_t* startT, const int32_t* endQ,
                            const int32_t* endT, const int64_t* offsets, int64_t dirStride, int64_t wsStride,
                            PairJob* jobs, hipStream_t stream);
-// Counting sort by tLen, longest first (maxLen <= kLongTarget: the bins fit LDS). bins: maxLen + 1 ints.
+// Counting sort by tLen, longest first (lengths are coarsened so that at most 8192 bins are needed).
+// bins: min(maxLen, 8191) + 1 ints.
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
                                   hipStream_t stream);
 // blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch

@@ -1289,20 +1289,44 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 RC_TRY(ws->get(kRI, (size_t)n * sizeof(int32_t), &ri));
                 RC_TRY(ws->get(kRJ, (size_t)n * sizeof(int32_t), &rj));
                 const DpRules rr{1, 1, 0, fr.region};
-                if (lanePerPair) {
+                // Which kernel scans the reversed prefixes. One strip: lane per pair (it stops at the
+                // first column that holds the optimum). More strips: no early stop, every job sweeps
+                // its whole prefix; a lane walks it alone (14 instructions per cell, but a wavefront
+                // lasts as long as its longest lane), a wavefront per pair spends 64 lanes on it
+                // (~50 instructions per 64-row column step). Rough cost of either, in ms, from the
+                // mean and the longest target of the database:
+                bool scanLanePerPair = lanePerPair;
+                if (lanePerPair && !oneStrip) {
+                    const double strips = (double)((queryLength + kLanes - 1) / kLanes);
+                    const double meanLen = (double)db->total / (double)std::max<int64_t>(db->count, 1);
+                    const double perLane = std::max((double)n * strips * meanLen * (14 * 4.5) / (1024 * 2.4e6),
+                                                    strips * (double)db->maxLen * (64 * 14 * 4.5) / 2.4e6);
+                    const double perWave = std::max((double)n * strips * (meanLen + 63) * 225.0 / (1024 * 2.4e6),
+                                                    strips * (double)(db->maxLen + 63) * 250.0 / 2.4e6);
+                    scanLanePerPair = perLane <= perWave;
+                }
+                if (scanLanePerPair) {
                     // chunks of whole wavefronts whose strip boundaries (8 B per column and pair) fit 4 GB
                     const int64_t chunk =
                         oneStrip ? n : std::max<int64_t>(kLanes, (4ll << 30) / (8 * db->maxLen) / kLanes * kLanes);
-                    void* pb = nullptr;
-                    if (!oneStrip)
-                        RC_TRY(ws->get(kPairB0, (size_t)((std::min(chunk, n) + kLanes - 1) / kLanes * kLanes) *
-                                                    db->maxLen * sizeof(int2), &pb));
+                    void *pb = nullptr, *pbins = nullptr, *psorted = nullptr;
+                    if (!oneStrip) {
+                        const int64_t most = std::min(chunk, n);
+                        RC_TRY(ws->get(kPairB0, (size_t)((most + kLanes - 1) / kLanes * kLanes) * db->maxLen * sizeof(int2), &pb));
+                        // prefixes of similar length share a wavefront (results stay addressed by job.out)
+                        RC_TRY(ws->get(kSortBins, (size_t)(std::min<int64_t>(db->maxLen, 8191) + 1) * sizeof(int), &pbins));
+                        RC_TRY(ws->get(kSortedJobs, (size_t)most * sizeof(PairJob), &psorted));
+                    }
                     for (int64_t c0 = 0; c0 < n; c0 += chunk) {
                         const int nc = (int)std::min<int64_t>(chunk, n - c0);
-                        PairJob* jobs = (PairJob*)pjobs + c0;
+                        const PairJob* jobs = (PairJob*)pjobs + c0;
                         HIP_TRY(launchReverseJobs(nc, (const int32_t*)ps + c0, (const int32_t*)pi + c0,
                                                   (const int32_t*)pj + c0, db->d_offsets + start + c0,
-                                                  packRules(rr), 0, jobs, stream));
+                                                  packRules(rr), 0, (PairJob*)pjobs + c0, stream));
+                        if (!oneStrip) {
+                            HIP_TRY(launchSortJobsByLength(jobs, nc, (int)db->maxLen, (int*)pbins, (PairJob*)psorted, stream));
+                            jobs = (const PairJob*)psorted;
+                        }
                         PerPairArgs pa = perPair;
                         pa.jobs = jobs;
                         pa.nJobs = nc;
@@ -1353,9 +1377,23 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 int64_t batch =
                     std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
                 void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
-                const bool sortJobs = lanePerPair && maxWindow <= kLongTarget;  // bins live in LDS
+                // Direction pass: one lane per pair needs ~64 x fewer instructions per cell but a
+                // lane walks its whole window alone (strips x columns x 64 rows, ~0.4 us per strip
+                // column); with few pairs per batch or huge windows (global alignments of long
+                // targets) a wavefront per pair is done sooner. Rough cost of either, in ms:
+                bool traceLanePerPair = lanePerPair;
+                if (lanePerPair) {
+                    const double batches = std::ceil((double)n / (double)batch);
+                    const double pairs = (double)std::min<int64_t>(batch, n);
+                    const double cells = (double)windowStrips * (double)(maxWindow + kLanes - 1);
+                    const double perLane = batches * std::ceil(pairs / kLanes / 2048.0) * cells * (64 * 21 * 4.5) / 2.4e6;
+                    const double perWave =
+                        batches * std::max(pairs * cells * 225.0 / (1024 * 2.4e6), cells * 250.0 / 2.4e6);
+                    traceLanePerPair = perLane <= perWave;
+                }
+                const bool sortJobs = traceLanePerPair;
                 if (sortJobs) {
-                    RC_TRY(ws->get(kSortBins, (size_t)(maxWindow + 1) * sizeof(int), &pbins));
+                    RC_TRY(ws->get(kSortBins, (size_t)(std::min<int64_t>(maxWindow, 8191) + 1) * sizeof(int), &pbins));
                     RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
                 }
                 // the direction workspace is the one allocation that can be refused on a GPU shared
@@ -1380,7 +1418,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                                             stream));
                     // job.out is relative to the batch: offset the score pointer
                     WalkArgs wa{};
-                    if (lanePerPair) {
+                    if (traceLanePerPair) {
                         // neighbours of similar length share a wavefront; results stay addressed by job.out
                         if (sortJobs) {
                             HIP_TRY(launchSortJobsByLength(jobs, nb, (int)maxWindow, (int*)pbins, (PairJob*)psorted,

@@ -470,14 +470,16 @@ __global__ __launch_bounds__(kGatherBlock) void gather_ops_kernel(int n, const u
 // perpair_kernel runs a wavefront until its longest pair is done: 64 neighbours of similar
 // length waste few columns, and the longest wavefronts start first.
 constexpr int kSortBlock = 1024;
+constexpr int kSortMaxBins = 8192;  // 32 KB of LDS
 
+// (keys are lengths >> shift, so that windows of any length sort with at most 8192 bins)
 __global__ __launch_bounds__(kSortBlock) void job_length_histogram_kernel(const PairJob* jobs, int n, int maxLen,
-                                                                          int* bins) {
+                                                                          int shift, int* bins) {
     extern __shared__ int local[];
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
     __syncthreads();
     for (int k = blockIdx.x * kSortBlock + threadIdx.x; k < n; k += gridDim.x * kSortBlock)
-        atomicAdd(&local[min(jobs[k].tLen, maxLen)], 1);
+        atomicAdd(&local[min(jobs[k].tLen >> shift, maxLen)], 1);
     __syncthreads();
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock)
         if (local[b]) atomicAdd(&bins[b], local[b]);
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
 // Scatter: a block ranks its jobs per length in LDS and reserves one range per (block, length)
 // with a single global atomic, instead of one contended atomic per job.
 __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const PairJob* jobs, int n, int maxLen,
-                                                                        int* bins, PairJob* sorted) {
+                                                                        int shift, int* bins, PairJob* sorted) {
     extern __shared__ int local[];
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
     __syncthreads();
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
     int key = 0, rank = 0;
     if (k < n) {
         j = jobs[k];
-        key = min(j.tLen, maxLen);
+        key = min(j.tLen >> shift, maxLen);
         rank = atomicAdd(&local[key], 1);
     }
     __syncthreads();
@@ -534,14 +536,17 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
                                   hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(bins, 0, (size_t)(maxLen + 1) * sizeof(int), stream);
+    int shift = 0;
+    while ((maxLen >> shift) >= kSortMaxBins) ++shift;
+    const int maxKey = maxLen >> shift;
+    hipError_t e = hipMemsetAsync(bins, 0, (size_t)(maxKey + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int blocks = std::min((n + kSortBlock - 1) / kSortBlock, 1024);
     hipLaunchKernelGGL(job_length_histogram_kernel, dim3(blocks), dim3(kSortBlock),
-                       (size_t)(maxLen + 1) * sizeof(int), stream, jobs, n, maxLen, bins);
-    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxLen, bins);
+                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins);
+    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins);
     hipLaunchKernelGGL(job_length_scatter_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
-                       (size_t)(maxLen + 1) * sizeof(int), stream, jobs, n, maxLen, bins, sorted);
+                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins, sorted);
     return hipGetLastError();
 }
 
