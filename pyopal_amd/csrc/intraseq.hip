@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
     partial[threadIdx.x] = sum;
     __syncthreads();
     for (int off = 1; off < kSortBlock; off <<= 1) {
-        const int v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
+        const int v = (int)threadIdx.x >= off ? partial[threadIdx.x - off] : 0;
         __syncthreads();
         partial[threadIdx.x] += v;
         __syncthreads();
