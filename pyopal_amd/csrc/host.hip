@@ -488,29 +488,36 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
                 vlen.push_back(std::min(window, L - s));
             }
         }
-        // longest first (stable: windows of one target stay in order)
-        std::vector<int32_t> order(ids.size());
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return vlen[a] > vlen[b]; });
-        std::vector<int32_t> ids2(ids.size()), seg2(ids.size()), len2(ids.size());
-        for (size_t x = 0; x < order.size(); ++x) {
-            ids2[x] = ids[order[x]];
-            seg2[x] = segStart[order[x]];
-            len2[x] = vlen[order[x]];
+    } else {
+        for (int64_t k = start; k < end; ++k) {
+            const int L = dbLen(db, k);
+            if (L > kLongTarget) {
+                v->longIds.push_back((int32_t)k);
+            } else {
+                ids.push_back((int32_t)k);
+                vlen.push_back(L);
+            }
+        }
+    }
+    {
+        // longest first: the heaviest wavefronts are dispatched first. Stable counting sort by
+        // length (windows of one target stay in order): O(n), where std::stable_sort cost most
+        // of the view construction for a million targets.
+        int longest = 0;
+        for (int32_t L : vlen) longest = std::max(longest, L);
+        std::vector<int64_t> first((size_t)longest + 2, 0);
+        for (int32_t L : vlen) ++first[(size_t)(longest - L) + 1];
+        for (size_t b = 1; b < first.size(); ++b) first[b] += first[b - 1];
+        std::vector<int32_t> ids2(ids.size()), seg2(segStart.size()), len2(ids.size());
+        for (size_t x = 0; x < ids.size(); ++x) {
+            const size_t at = (size_t)first[(size_t)(longest - vlen[x])]++;
+            ids2[at] = ids[x];
+            len2[at] = vlen[x];
+            if (!segStart.empty()) seg2[at] = segStart[x];
         }
         ids.swap(ids2);
         segStart.swap(seg2);
         vlen.swap(len2);
-    } else {
-        for (int64_t k = start; k < end; ++k) {
-            if (dbLen(db, k) > kLongTarget) v->longIds.push_back((int32_t)k);
-            else ids.push_back((int32_t)k);
-        }
-        // longest first: the heaviest wavefronts are dispatched first
-        std::stable_sort(ids.begin(), ids.end(),
-                         [&](int32_t a, int32_t b) { return dbLen(db, a) > dbLen(db, b); });
-        vlen.resize(ids.size());
-        for (size_t k = 0; k < ids.size(); ++k) vlen[k] = dbLen(db, ids[k]);
     }
     v->nPacked = (int)ids.size();
     v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
