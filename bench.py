@@ -60,6 +60,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # leave the collective's kernels a few CUs beside the persistent search kernel, so that
+        # the gather of one step really runs during the next step's search
+        os.environ.setdefault("MIOPAL_RESERVE_CUS", "8")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))

@@ -989,7 +989,13 @@ struct Search {
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
                 ia.workCounter = (int*)wc;
-                if (launchInterseqPair(ia, rows, halfFloat, db->computeUnits, stream) != hipSuccess) {
+                // The persistent workgroups fill every CU (LDS and registers): a kernel of another
+                // stream - the collective that gathers the previous search's scores - would wait for
+                // them to leave. MIOPAL_RESERVE_CUS keeps a few CUs out of the launch for it.
+                int pairUnits = db->computeUnits;
+                if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
+                    pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
+                if (launchInterseqPair(ia, rows, halfFloat, pairUnits, stream) != hipSuccess) {
                     // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant
                     (void)hipGetLastError();
                     HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
