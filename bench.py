@@ -86,31 +86,19 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     on_device = backend == "nccl"
-    gathered = [None, None]
-    if world > 1 and rank == 0:
-        gathered = [[torch.empty_like(out) if on_device else torch.empty(N, dtype=torch.int32)
-                     for _ in range(world)] for _ in range(2)]
-    pending = [None, None]
-    counter = [0]
+    from pyopal_amd.shard import OverlappedGather
+    pipe = OverlappedGather(outs, dst=0, on_device=on_device)
 
     def step():
-        b = counter[0] & 1
-        counter[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()  # the gather that read this buffer two steps ago (stream-ordered for RCCL)
-            pending[b] = None
-        db.search_device_scores(query, matrix, outs[b].data_ptr(), stream, 3, 1, "sw")
-        if world > 1:
-            # the one exchange of the path: per-shard scores to rank 0 (RCCL over xGMI). Issued
-            # asynchronously: it waits for the search on the current stream, then runs on the
-            # collective's own stream while the next step's search starts.
-            pending[b] = dist.gather(outs[b] if on_device else outs[b].cpu(), gathered[b], dst=0, async_op=True)
+        b, buf = pipe.acquire()  # waits (stream-ordered for RCCL) for the gather that read it last
+        db.search_device_scores(query, matrix, buf.data_ptr(), stream, 3, 1, "sw")
+        # the one exchange of the path: per-shard scores to rank 0 (RCCL over xGMI). Issued
+        # asynchronously: it waits for the search on the current stream, then runs on the
+        # collective's own stream while the next step's search starts.
+        pipe.submit(b)
 
     def fence():
-        for b in (0, 1):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        pipe.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -124,7 +112,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    last = (counter[0] - 1) & 1 if counter[0] else 0   # buffer of the last step
+    last = pipe.last   # buffer of the last step
     out = outs[last]
     n_launch, kernel_ms = db.last_kernel_time()
     db.set_profiling(False)
@@ -135,7 +123,7 @@ def main():
         elapsed = float(t.item())
         if rank == 0:
             # the gathered vector of this rank's own shard is what the search wrote
-            assert torch.equal(gathered[last][0].cpu(), out.cpu())
+            assert torch.equal(pipe.received[last][0].cpu(), out.cpu())
 
     # (correctness gate: in the cpu_baseline leg below - every score against the AVX2 port,
     # a sample against the scalar checker; the other legs never touch the code under oracle/)

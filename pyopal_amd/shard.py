@@ -46,3 +46,53 @@ def gather_scores(local, bounds: typing.Sequence[int], dst: int = 0):
     if rank != dst:
         return None
     return torch.cat([g[:s] for g, s in zip(gathered, sizes)])
+
+
+class OverlappedGather:
+    """The gather of one search's scores, issued asynchronously so that it runs beside the next
+    search (`bench.py`): `slots` result buffers are used in turn; `acquire()` hands out the next
+    one after waiting for the gather that last read it, `submit()` starts the gather of the
+    buffer just filled, `drain()` waits for everything in flight. With the ``nccl`` backend a
+    wait orders the current stream behind the collective's stream; with ``gloo`` (CPU tests,
+    rehearsals) tensors go through host copies.
+    """
+
+    def __init__(self, buffers, dst: int = 0, on_device: bool = True):
+        import torch
+        import torch.distributed as dist
+
+        self._dist = dist
+        self.buffers = list(buffers)
+        self.dst = dst
+        self.on_device = on_device
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.pending = [None] * len(self.buffers)
+        self.received = [None] * len(self.buffers)
+        if self.world > 1 and self.rank == dst:
+            like = self.buffers[0] if on_device else self.buffers[0].cpu()
+            self.received = [[torch.empty_like(like) for _ in range(self.world)] for _ in self.buffers]
+        self._next = 0
+        self.last = 0
+
+    def acquire(self):
+        """-> (index, buffer) of the next result buffer, free to be overwritten."""
+        b = self._next
+        self._next = (b + 1) % len(self.buffers)
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.last = b
+        return b, self.buffers[b]
+
+    def submit(self, b: int) -> None:
+        if self.world == 1:
+            return
+        tensor = self.buffers[b] if self.on_device else self.buffers[b].cpu()
+        self.pending[b] = self._dist.gather(tensor, self.received[b], dst=self.dst, async_op=True)
+
+    def drain(self) -> None:
+        for b, work in enumerate(self.pending):
+            if work is not None:
+                work.wait()
+                self.pending[b] = None

@@ -36,6 +36,23 @@ WORKER = textwrap.dedent("""
         assert np.array_equal(full.numpy(), want), "gathered scores differ"
         assert bounds[0] == 0 and bounds[-1] == 101 and all(b > a for a, b in zip(bounds, bounds[1:]))
         print("SHARD_OK", bounds)
+
+    # the overlapped gather of bench.py: two buffers in turn, asynchronous collectives
+    bufs = [torch.zeros(1000, dtype=torch.int32) for _ in range(2)]
+    pipe = shard.OverlappedGather(bufs, dst=0, on_device=False)
+    seen = {}
+    for step in range(7):
+        b, buf = pipe.acquire()
+        buf.fill_(step * 100 + rank)          # "the search" of this step
+        pipe.submit(b)
+        seen[b] = step
+    pipe.drain()
+    if rank == 0:
+        for b, step in seen.items():
+            for r in range(world):
+                assert torch.all(pipe.received[b][r] == step * 100 + r), (b, step, r)
+        assert pipe.last == 0 and seen == {0: 6, 1: 5}
+        print("PIPE_OK")
     dist.destroy_process_group()
 """)
 
@@ -54,7 +71,7 @@ def test_two_rank_gather(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "SHARD_OK" in out.stdout
+    assert "SHARD_OK" in out.stdout and "PIPE_OK" in out.stdout
 
 
 def test_balanced_bounds_unit():
