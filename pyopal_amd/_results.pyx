@@ -10,7 +10,7 @@ is the second hot loop of the path once the DP itself runs on the GPU
 Python-level call per target.
 """
 
-from cpython.bytes cimport PyBytes_FromStringAndSize
+cimport cython
 from cpython.list cimport PyList_New, PyList_SET_ITEM
 from cpython.ref cimport Py_INCREF
 from libc.stdint cimport int32_t, int64_t, uint8_t
@@ -19,28 +19,23 @@ cdef dict _OPAL_ALIGNMENT_OPERATION = {"M": 0, "D": 1, "I": 2, "X": 3}   # src/p
 cdef bytes _OPS_TO_TEXT = bytes.maketrans(bytes([0, 1, 2, 3]), b"MDIX")   # src/pyopal/lib.pyx:991
 
 
+# (no_gc: the only object a result refers to is the shared buffer of operations, which refers to
+# no result - a million results tracked by the cyclic collector made building the list 13x slower)
+@cython.no_gc
 cdef class ScoreResult:
     """Result of a search in ``score`` mode (``src/pyopal/lib.pyx:783-834``)."""
 
+    # (each class carries only its own fields - the reference embeds one OpalSearchResult in the
+    # base class, src/pyopal/lib.pxd:113-115; a million 32-byte objects build faster than a
+    # million 88-byte ones)
     cdef Py_ssize_t _target_index
     cdef bint       _score_set
     cdef int        _score
-    cdef int        _query_end
-    cdef int        _target_end
-    cdef int        _query_start
-    cdef int        _target_start
-    cdef int        _query_length
-    cdef int        _target_length
-    cdef bytes      _ops
 
     def __cinit__(self):
         self._target_index = -1
         self._score_set = False
         self._score = 0
-        self._query_end = self._target_end = -1
-        self._query_start = self._target_start = -1
-        self._query_length = self._target_length = -1
-        self._ops = None
 
     def __init__(self, size_t target_index, int score):
         self._target_index = target_index
@@ -73,8 +68,15 @@ cdef class ScoreResult:
         return self._score
 
 
+@cython.no_gc
 cdef class EndResult(ScoreResult):
     """Result of a search in ``end`` mode (``src/pyopal/lib.pyx:837-881``)."""
+
+    cdef int        _query_end
+    cdef int        _target_end
+
+    def __cinit__(self):
+        self._query_end = self._target_end = -1
 
     def __init__(self, size_t target_index, int score, int query_end, int target_end):
         super().__init__(target_index, score)
@@ -101,8 +103,26 @@ cdef class EndResult(ScoreResult):
         return self._target_end
 
 
+@cython.no_gc
 cdef class FullResult(EndResult):
     """Result of a search in ``full`` mode (``src/pyopal/lib.pyx:884-1119``)."""
+
+    cdef int        _query_start
+    cdef int        _target_start
+    cdef int        _query_length
+    cdef int        _target_length
+    cdef bytes      _ops
+    # alignments of a bulk search live in one shared buffer until somebody looks at them
+    cdef object     _ops_owner
+    cdef Py_ssize_t _ops_offset
+    cdef Py_ssize_t _ops_length
+
+    def __cinit__(self):
+        self._query_start = self._target_start = -1
+        self._query_length = self._target_length = -1
+        self._ops = None
+        self._ops_owner = None
+        self._ops_offset = self._ops_length = 0
 
     def __init__(self, size_t target_index, int score, int query_end, int target_end,
                  int query_start, int target_start, int query_length, int target_length,
@@ -150,18 +170,26 @@ cdef class FullResult(EndResult):
         assert self._target_length >= 0
         return self._target_length
 
+    cdef bytes _operations(self):
+        # op codes of src/pyopal/opal.pxd:21-24, one byte each
+        if self._ops is None and self._ops_owner is not None:
+            self._ops = bytes(self._ops_owner[self._ops_offset:self._ops_offset + self._ops_length])
+            self._ops_owner = None
+        return self._ops
+
     @property
     def alignment(self):
         """`str`: The operations over ``MDIX`` (D: query residue against a gap,
         I: target residue against a gap)."""
-        if self._ops is None:
+        cdef bytes ops = self._operations()
+        if ops is None:
             return ""
-        return self._ops.translate(_OPS_TO_TEXT).decode("ascii")
+        return ops.translate(_OPS_TO_TEXT).decode("ascii")
 
     cpdef str cigar(self):
         """CIGAR string in SAM convention (``op % 3`` -> ``M, I, D``); `None` when
         the alignment is empty."""
-        cdef bytes ops = self._ops
+        cdef bytes ops = self._operations()
         cdef Py_ssize_t i, n
         cdef unsigned char symbol, current
         cdef size_t count
@@ -185,17 +213,19 @@ cdef class FullResult(EndResult):
     cpdef float identity(self):
         """Fraction of aligned residue pairs that are identical (float32 arithmetic,
         ``src/pyopal/lib.pyx:1039-1052``)."""
-        assert self._ops is not None
-        cdef int matches = self._ops.count(0)
-        cdef int mismatches = self._ops.count(3)
+        cdef bytes ops = self._operations()
+        assert ops is not None
+        cdef int matches = ops.count(0)
+        cdef int mismatches = ops.count(3)
         return (<float> matches) / (<float> (matches + mismatches))
 
     cpdef float coverage(self, str reference="query"):
         """Fraction of the reference sequence covered by the alignment; edge
         operations that are gaps in the reference do not count
         (``src/pyopal/lib.pyx:1054-1119``)."""
-        assert self._ops is not None
-        cdef Py_ssize_t i, n = len(self._ops)
+        cdef bytes ops = self._operations()
+        assert ops is not None
+        cdef Py_ssize_t i, n = len(ops)
         cdef Py_ssize_t length, reflength
         cdef unsigned char operation
         if reference == "query":
@@ -209,12 +239,12 @@ cdef class FullResult(EndResult):
         else:
             raise ValueError(f"Invalid coverage reference: {reference!r}")
         for i in range(n):
-            if <unsigned char> self._ops[i] == operation:
+            if <unsigned char> ops[i] == operation:
                 length -= 1
             else:
                 break
         for i in range(n - 1, -1, -1):
-            if <unsigned char> self._ops[i] == operation:
+            if <unsigned char> ops[i] == operation:
                 length -= 1
             else:
                 break
@@ -263,7 +293,7 @@ def full_results(Py_ssize_t start, const int32_t[::1] scores, const int32_t[::1]
     cdef Py_ssize_t k, n = scores.shape[0]
     cdef list out = PyList_New(n)
     cdef FullResult r
-    cdef const char* base = <const char*> &ops[0] if ops.shape[0] > 0 else NULL
+    cdef object owner = memoryview(ops)   # one shared view of the flat buffer
     for k in range(n):
         r = FullResult.__new__(FullResult)
         r._target_index = start + k
@@ -275,10 +305,10 @@ def full_results(Py_ssize_t start, const int32_t[::1] scores, const int32_t[::1]
         r._target_start = start_t[k]
         r._query_length = query_length
         r._target_length = target_lengths[start + k]
-        if base != NULL:
-            r._ops = PyBytes_FromStringAndSize(base + ops_off[k], ops_off[k + 1] - ops_off[k])
-        else:
-            r._ops = b""
+        # no bytes object per target here: the operations stay in the shared buffer until used
+        r._ops_owner = owner
+        r._ops_offset = ops_off[k]
+        r._ops_length = ops_off[k + 1] - ops_off[k]
         Py_INCREF(r)
         PyList_SET_ITEM(out, k, r)
     return out
