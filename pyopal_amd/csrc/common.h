@@ -76,6 +76,12 @@ struct IntraseqArgs {
     int32_t* endI;            // query coordinate of the best cell (pass coordinates)
     int32_t* endJ;            // target coordinate
     int raisePriority;        // run the wavefronts at s_setprio 3 (side-stream launches)
+    // Hybrid direction pass: the job list is sorted longest first and this kernel takes only its
+    // head, the first *headWaves x 64 jobs (the rest belongs to perpair_kernel); their direction
+    // bytes and strip boundaries are then addressed by position, not by job.dirOff / job.wsOff.
+    const int* headWaves;     // null: every job, addressed through the job itself
+    int64_t headDirStride;    // direction bytes per job
+    int64_t headWsStride;     // boundary columns per job
 };
 
 struct WalkArgs {
@@ -92,6 +98,11 @@ struct WalkArgs {
     // > 0 = perpair_kernel ([strip][j][i][lane] per 64 consecutive jobs, this many bytes apart)
     int64_t dirWaveStride;
     int64_t dirStripColumns;  // columns per strip in the perpair_kernel layout
+    // hybrid direction pass: jobs at positions below *headWaves x 64 have intraseq_kernel's layout
+    // in `headDirs`, headDirStride bytes per job
+    const int* headWaves;
+    const uint8_t* headDirs;
+    int64_t headDirStride;
     int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
     int queryLength;          // whole query (staged in LDS when it fits)
 };
@@ -115,6 +126,8 @@ struct PerPairArgs {
     int64_t dirStripColumns;  // columns reserved per strip (>= longest target window)
     int2* boundary;           // query windows of more than 64 rows: [job / 64][column][job % 64]
     int64_t boundaryStride;   // columns per 64 consecutive jobs (>= longest target window)
+    const int* skipWaves;     // hybrid direction pass: the first *skipWaves wavefronts' jobs belong to
+                              // intraseq_kernel (null: none)
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 
@@ -169,8 +182,11 @@ hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_
                            PairJob* jobs, hipStream_t stream);
 // Counting sort by tLen, longest first (lengths are coarsened so that at most 8192 bins are needed).
 // bins: min(maxLen, 8191) + 1 ints.
+// headWaves (optional): receives how many leading wavefronts of 64 sorted jobs are outliers - more
+// than twice as long as the 90th percentile - capped at maxHeadWaves: a lane-per-pair wavefront
+// lasts as long as its longest lane, those few go to the wavefront-per-pair kernel instead.
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
-                                  hipStream_t stream);
+                                  hipStream_t stream, int* headWaves = nullptr, int maxHeadWaves = 0);
 // blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
                            int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,

@@ -143,7 +143,7 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kSlots
 };
 
 struct Workspace {
@@ -699,11 +699,16 @@ struct Search {
 
     // Same with a job list that already sits in HBM. wsStride > 0: the jobs' query pieces may have
     // more than 64 rows, job k owns wsStride strip-boundary columns at wsOff = k * wsStride.
+    // headWaves: only the first *headWaves x 64 jobs (hybrid direction pass), addressed by position.
     int runDeviceJobs(const PairJob* d_jobs, int nJobs, int32_t* d_score, int32_t* d_endI, int32_t* d_endJ,
-                      bool trace = false, uint8_t* d_dirs = nullptr, int64_t wsStride = 0) {
+                      bool trace = false, uint8_t* d_dirs = nullptr, int64_t wsStride = 0,
+                      const int* headWaves = nullptr, int64_t headDirStride = 0) {
         if (nJobs <= 0) return 0;
         RC_TRY(ensurePairInputs());
         IntraseqArgs a{};
+        a.headWaves = headWaves;
+        a.headDirStride = headDirStride;
+        a.headWsStride = wsStride;
         if (wsStride > 0) {
             void *b0, *b1;
             RC_TRY(ws->get(kPairB0, (size_t)nJobs * wsStride * sizeof(int2), &b0));
@@ -1404,7 +1409,21 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                         batches * std::max(pairs * cells * 225.0 / (1024 * 2.4e6), cells * 250.0 / 2.4e6);
                     traceLanePerPair = perLane <= perWave;
                 }
+                if (pt.on)
+                    fprintf(stderr, "[miopal]   traceback: longest window %lld columns, %lld strip(s) of rows, %lld pairs per batch, %s per pair\n",
+                            (long long)maxWindow, (long long)windowStrips, (long long)batch,
+                            traceLanePerPair ? "lane" : "wavefront");
                 const bool sortJobs = traceLanePerPair;
+                // hybrid: up to 2 GB of direction bytes for the outliers a wavefront-per-pair pass takes
+                int64_t maxHead = 0;
+                void *phead = nullptr, *pheadDirs = nullptr;
+                if (sortJobs && !getenv("MIOPAL_NO_HYBRID_TRACE")) {
+                    maxHead = std::min<int64_t>((2ll << 30) / slotDir / kLanes, (batch + kLanes - 1) / kLanes);
+                    if (maxHead > 0) {
+                        RC_TRY(ws->get(kHeadWaves, sizeof(int), &phead));
+                        if (!ws->tryGet(kHeadDirs, (size_t)(maxHead * kLanes * slotDir), &pheadDirs)) maxHead = 0;
+                    }
+                }
                 if (sortJobs) {
                     RC_TRY(ws->get(kSortBins, (size_t)(std::min<int64_t>(maxWindow, 8191) + 1) * sizeof(int), &pbins));
                     RC_TRY(ws->get(kSortedJobs, (size_t)batch * sizeof(PairJob), &psorted));
@@ -1435,11 +1454,22 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                         // neighbours of similar length share a wavefront; results stay addressed by job.out
                         if (sortJobs) {
                             HIP_TRY(launchSortJobsByLength(jobs, nb, (int)maxWindow, (int*)pbins, (PairJob*)psorted,
-                                                           stream));
+                                                           stream, (int*)phead, (int)maxHead));
                             jobs = (PairJob*)psorted;
                             wa.slotByOut = 1;
                         }
                         PerPairArgs pa = perPair;
+                        if (maxHead > 0) {
+                            // outliers at the head of the sorted list: one wavefront per pair
+                            const int nh = (int)std::min<int64_t>(nb, maxHead * kLanes);
+                            RC_TRY(s.runDeviceJobs(jobs, nh, (int32_t*)pts + b0, nullptr, nullptr, true,
+                                                   (uint8_t*)pheadDirs, windowStrips > 1 ? maxWindow : 0,
+                                                   (const int*)phead, slotDir));
+                            pa.skipWaves = (const int*)phead;
+                            wa.headWaves = (const int*)phead;
+                            wa.headDirs = (const uint8_t*)pheadDirs;
+                            wa.headDirStride = slotDir;
+                        }
                         pa.jobs = jobs;
                         pa.nJobs = nb;
                         pa.dirs = (uint8_t*)pd;

@@ -41,8 +41,14 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     const int lane = threadIdx.x & 63;
     const int jobIdx = blockIdx.x * kJobsPerBlock + wave;
     if (jobIdx >= a.nJobs) return;  // wave-uniform, after the only barrier
+    const bool headOnly = a.headWaves != nullptr;
+    if (headOnly && jobIdx >= *a.headWaves * kLanes) return;
 
-    const PairJob job = a.jobs[jobIdx];
+    PairJob job = a.jobs[jobIdx];
+    if (headOnly) {
+        job.dirOff = (int64_t)jobIdx * a.headDirStride;
+        job.wsOff = (int64_t)jobIdx * a.headWsStride;
+    }
     const int Q = job.qLen, L = job.tLen;
     // a pair is a chain of L + 63 dependent steps: beside the packed kernel (side stream)
     // it should win the SIMD's issue arbitration, it needs few slots
@@ -233,8 +239,11 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
     const PairJob job = a.jobs[idx];
     const int n = job.qLen, m = job.tLen;
     const int nSteps = m + kLanes - 1;
-    const bool laneMajor = a.dirWaveStride > 0;
-    const uint8_t* dirs = laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
+    // hybrid direction pass: the head of the sorted list was done by intraseq_kernel
+    const bool head = a.headWaves != nullptr && idx < *a.headWaves * kLanes;
+    const bool laneMajor = a.dirWaveStride > 0 && !head;
+    const uint8_t* dirs = head ? a.headDirs + (int64_t)idx * a.headDirStride
+                        : laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
                                     : a.dirs + job.dirOff;
     const uint8_t* q = a.query + job.qOff;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
@@ -486,7 +495,8 @@ __global__ __launch_bounds__(kSortBlock) void job_length_histogram_kernel(const 
 }
 
 // bins[b] <- first position of length b in the sorted order (lengths descending); one block
-__global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxLen, int* bins) {
+__global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxLen, int* bins, int n, int shift,
+                                                                        int* headWaves, int maxHeadWaves) {
     __shared__ int partial[kSortBlock];
     const int nBins = maxLen + 1;
     const int per = (nBins + kSortBlock - 1) / kSortBlock;
@@ -506,6 +516,20 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
         const int c = bins[maxLen - r];
         bins[maxLen - r] = run;
         run += c;
+    }
+    if (headWaves != nullptr) {
+        // bins[b] is now the number of jobs with a key above b. Outliers: keys above twice the
+        // 90th percentile (and above 64 residues).
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int p90 = maxLen;
+            while (p90 > 0 && bins[p90 - 1] <= n / 10) --p90;   // smallest key with <= 10 % above it
+            const int floorKey = 64 >> shift;
+            const int longKey = max(2 * p90, floorKey) + 1;      // outliers have key >= longKey
+            int count = 0;
+            if (longKey <= maxLen) count = longKey >= 1 ? bins[longKey - 1] : n;
+            *headWaves = min((count + kLanes - 1) / kLanes, maxHeadWaves);
+        }
     }
 }
 
@@ -534,7 +558,7 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
 }
 
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int* headWaves, int maxHeadWaves) {
     if (n <= 0) return hipSuccess;
     int shift = 0;
     while ((maxLen >> shift) >= kSortMaxBins) ++shift;
@@ -544,7 +568,8 @@ hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* b
     const int blocks = std::min((n + kSortBlock - 1) / kSortBlock, 1024);
     hipLaunchKernelGGL(job_length_histogram_kernel, dim3(blocks), dim3(kSortBlock),
                        (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins);
-    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins);
+    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins, n, shift,
+                       headWaves, maxHeadWaves);
     hipLaunchKernelGGL(job_length_scatter_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
                        (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins, sorted);
     return hipGetLastError();

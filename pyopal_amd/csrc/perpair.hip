@@ -47,7 +47,8 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * kBlock + threadIdx.x;
-    const bool active = idx < a.nJobs;
+    // (hybrid direction pass: the leading wavefronts' jobs are outliers done by intraseq_kernel)
+    const bool active = idx < a.nJobs && !(a.skipWaves != nullptr && (idx >> 6) < *a.skipWaves);
     PairJob job{};
     if (active) job = a.jobs[idx];
     const int Q = job.qLen, L = job.tLen;
