@@ -132,7 +132,8 @@ def test_alternative_kernel_variants(capi, monkeypatch, switch):
                 compare(gpu, ref, mode, f"{switch} {algo}/{mode} Q={qlen}")
 
 
-@pytest.mark.parametrize("switch", ["MIOPAL_HOST_TRACEBACK", "MIOPAL_NO_PERPAIR", "MIOPAL_NO_SIDE_STREAM"])
+@pytest.mark.parametrize("switch", ["MIOPAL_HOST_TRACEBACK", "MIOPAL_NO_PERPAIR", "MIOPAL_NO_SIDE_STREAM",
+                                    "MIOPAL_NO_HYBRID_TRACE"])
 def test_alternative_full_mode_paths(capi, monkeypatch, switch):
     # fallbacks of `full`: traceback batches built on the host, wavefront-per-pair kernels for
     # one-strip queries, long targets recomputed after (not beside) the packed kernel
@@ -468,3 +469,33 @@ def test_segmented_view_with_lanes_leaving_the_half_float_range(capi):
             np.testing.assert_array_equal(end[key][sample], ref[key], err_msg=key)
     finally:
         db.close()
+
+
+def test_outlier_windows_in_the_direction_pass(capi):
+    """A few long alignments among many short ones: the head of the sorted job list goes to the
+    wavefront-per-pair kernel, the rest to the lane-per-pair kernel (host.hip, headWaves) - the
+    alignments of both parts must equal the checker's."""
+    rng = np.random.default_rng(99)
+    n = 30_000
+    res, off = _data.random_db(rng, np.full(n, 300))
+    q = _data.random_protein(rng, 200)
+    homologs = rng.choice(n, size=150, replace=False)
+    for k in homologs:                      # noisy copies of the query: alignments of ~200 columns
+        copy = _data.mutate(rng, q, 0.2)[:290]
+        at = int(rng.integers(0, 300 - len(copy) + 1))
+        res[off[k] + at:off[k] + at + len(copy)] = copy
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(q, B62, 11, 1, "full", "sw")
+    finally:
+        db.close()
+    sample = np.unique(np.concatenate([homologs, rng.integers(0, n, size=400)]))
+    sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+    ref = _oracle.search(q, sres, soff, B62, 11, 1, "full", "sw")
+    spans = ref["end_t"] - ref["start_t"] + 1
+    planted = np.isin(sample, homologs)
+    assert np.median(spans[planted]) > 2 * np.percentile(spans[~planted], 90), "the test needs outliers"
+    for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+        np.testing.assert_array_equal(got[key][sample], ref[key], err_msg=key)
+    for x, k in enumerate(sample):
+        assert got["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
