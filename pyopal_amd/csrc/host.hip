@@ -80,13 +80,14 @@ struct PhaseTimer {
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 2ll << 30;  // bytes of direction workspace per traceback batch
 constexpr int64_t kInt32Safe = 1ll << 29;
-constexpr int kMaxDirectRecompute = 2048;
+constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
 // A lane that owns a whole target walks its columns one after the other (about 0.8 us per
 // column of 56 rows): whatever the number of targets, the lane-per-target kernels need
 // (longest target) x that. Few targets of a one-strip query are done sooner by the
 // wavefront-per-pair kernel, whose anti-diagonal step is ~10x shorter and which still has a
 // wavefront for every pair at this count.
-constexpr int64_t kSmallSearch = 4096;  // saturated half-float lanes sent straight to int32
+constexpr int64_t kSmallSearch = 4096;
+constexpr size_t kParkedWorkspaceBytes = 64ull << 30;  // idle per-handle workspaces kept at most
 
 // malloc-backed byte buffer: grows without zero-filling, and its storage can be handed to the
 // caller of the C ABI (who frees it with free()).
@@ -407,8 +408,15 @@ struct WorkspaceLease {
     }
     ~WorkspaceLease() {
         if (owned && ws) {
+            // Idle workspaces keep their buffers for the next search on whatever thread comes
+            // first, but not without bound: many threads that each ran one `full` search would
+            // otherwise park tens of GB apiece (the reference's thread pools default to one
+            // thread per CPU core). Beyond 64 GB of parked buffers this one is released.
+            std::unique_ptr<Workspace> mine(ws);
             std::lock_guard<std::mutex> g(db->wsMutex);
-            db->ownedFree.emplace_back(ws);
+            size_t parked = mine->bytes();
+            for (const auto& w : db->ownedFree) parked += w->bytes();
+            if (parked <= kParkedWorkspaceBytes || db->ownedFree.empty()) db->ownedFree.emplace_back(std::move(mine));
         }
     }
 };
