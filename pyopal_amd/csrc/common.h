@@ -158,8 +158,19 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
                           bool locate, hipStream_t stream);
 // pair-indexed LDS profile (single strip, Smith-Waterman); false = table does not fit LDS
 bool interseqPairFits(int rowsPerStrip, int nSymbols);
-hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, int computeUnits,
+enum PairFlavour : int {
+    kPairSwInt16 = 0,   // saturating int16
+    kPairSwHalf = 1,    // packed half floats, exact below 2048
+    kPairSwBiased = 2   // biased integer halves compared as half floats, column-shifted (interseq_impl.h)
+};
+// limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
+constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
+constexpr int kBiasedMaxMagnitude = 1024;  // |score|, open - ext, ext - open
+constexpr int kBiasedMaxExt = 512;
+constexpr int kBiasedPad = -1024;          // = kBiasedPadScore: padding symbol / rows in the profile
+hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream);
+hipError_t launchInterseqPairSwBiased(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);

@@ -884,7 +884,22 @@ struct Search {
             // modes use signed int16 lanes; whether a target fits is known from its length:
             //   every true H, E, F >= -(3*open + (Q + L)*ext)   and   H <= min(Q, L)*maxScore
             const bool sw = mode == OPAL_MODE_SW;
-            const bool halfFloat = sw && useHalf && maxScore <= 1024 && minScore >= -1024;
+            const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
+            // one strip + Smith-Waterman scores: the pair-indexed LDS profile saves the v_perm per cell
+            const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
+            const bool usePair = sw && !locate && nStrips == 1 && !(noPair && noPair[0] == '1') &&
+                                 interseqPairFits(rows, nSym);
+            // first rung of the pair-table kernel: biased integer halves (exact below 25600,
+            // interseq_impl.h) when the scores and gap costs leave its guard band alone
+            const bool biased = usePair && useHalf && maxScore <= kBiasedMaxMagnitude &&
+                                minScore >= -kBiasedMaxMagnitude && ext <= kBiasedMaxExt &&
+                                open - ext <= kBiasedMaxMagnitude && ext - open <= kBiasedMaxMagnitude &&
+                                !getenv("MIOPAL_NO_BIASED");
+            // Half floats turn a sum above 65504 into +inf, and inf + (-inf padding) into NaN, which
+            // the flag `best >= 2048` would miss (NaN converts to 0): only matrices whose best
+            // possible score stays finite take the half-float rung.
+            const bool halfFloat = sw && useHalf && !biased && maxScore <= 1024 && minScore >= -1024 &&
+                                   (int64_t)std::min<int64_t>(Q, db->maxLen) * std::max(maxScore, 0) < 60000;
             InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
             int profileShift = 0;
             if (!sw) {
@@ -921,7 +936,7 @@ struct Search {
                 memcpy(&bits, &h, sizeof bits);
                 return bits;
             };
-            const int16_t padValue = halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
+            const int16_t padValue = biased ? (int16_t)kBiasedPad : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
                 for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t] + profileShift);
@@ -948,7 +963,7 @@ struct Search {
             RC_TRY(ws->stageUpload(pp, prof.data(), prof.size() * sizeof(prof[0]), stream));
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
             const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
-            const int64_t limit = halfFloat ? 2048 : 32767;
+            const int64_t limit = biased ? kBiasedScoreLimit : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
@@ -969,7 +984,6 @@ struct Search {
             ia.region = r.region;
             ia.lens = view->d_lens;
             ia.score = (int32_t*)vs;
-            const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
             if (locate) {
                 void *vi, *vj;
                 RC_TRY(ws->get(kViewEndI, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), &vi));
@@ -995,9 +1009,8 @@ struct Search {
                 HIP_TRY(hipEventCreate(&e1));
                 HIP_TRY(hipEventRecord(e0, stream));
             }
-            // one strip + Smith-Waterman: the pair-indexed LDS profile saves the v_perm per cell
-            const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
-            if (sw && !locate && nStrips == 1 && !(noPair && noPair[0] == '1') && interseqPairFits(rows, nSym)) {
+            g_lastRouting[1] = 1;  // general kernel
+            if (usePair) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
@@ -1008,9 +1021,18 @@ struct Search {
                 int pairUnits = db->computeUnits;
                 if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
-                if (launchInterseqPair(ia, rows, halfFloat, pairUnits, stream) != hipSuccess) {
-                    // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant
+                const PairFlavour pf = biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
+                g_lastRouting[1] = 2 + (int)pf;
+                const hipError_t pe = launchInterseqPair(ia, rows, pf, pairUnits, stream);
+                if (pe != hipSuccess) {
+                    // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant (the
+                    // biased profile is a plain int16 profile whose padding score, -1024, cannot raise
+                    // a Smith-Waterman maximum either)
                     (void)hipGetLastError();
+                    g_lastRouting[1] |= 16;
+                    if (getenv("MIOPAL_VERBOSE"))
+                        fprintf(stderr, "miopal: pair-table kernel refused (%s), using the general kernel\n",
+                                hipGetErrorString(pe));
                     HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
                 }
             } else {
@@ -1050,7 +1072,7 @@ struct Search {
                 int32_t count = 0;
                 RC_TRY(ws->stageDownload(&count, ct, sizeof(int32_t)));
                 RC_TRY(ws->finishDownloads());
-                if (halfFloat && count > kMaxDirectRecompute) {
+                if ((halfFloat || biased) && count > kMaxDirectRecompute) {
                     // many targets left the half-float range: second rung, int16 lanes,
                     // over the whole view (its results overwrite the first pass)
                     return scorePassImpl(d_score, d_endI, d_endJ, false);

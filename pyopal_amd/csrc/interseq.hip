@@ -31,11 +31,15 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols) {
     return bytes <= 158 * 1024;  // leaves the runtime a little of the 160 KB
 }
 
-hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, bool halfFloat, int computeUnits,
+hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream) {
     if (a.nGroups <= 0) return hipSuccess;
-    return halfFloat ? launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream)
-                     : launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
+    switch (flavour) {
+        case kPairSwBiased: return launchInterseqPairSwBiased(a, rowsPerStrip, computeUnits, stream);
+        case kPairSwHalf: return launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream);
+        case kPairSwInt16: return launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace miopal

@@ -766,15 +766,28 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_kernel(Inte
     }
 }
 
+// per-device: hipFuncSetAttribute applies to the current device only
+static inline bool firstUseOnThisDevice(uint64_t* seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const uint64_t bit = 1ull << dev;
+    const uint64_t old = __atomic_fetch_or(seen, bit, __ATOMIC_RELAXED);
+    return !(old & bit);
+}
+
 template <int R, typename Arith>
 static hipError_t launchPairR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
     const size_t lds = PairLayout<R>::bytes(a.nSymbols);
-    static bool configured = false;  // benign race: the attribute is idempotent
-    if (!configured) {
+    static uint64_t configured = 0;  // one bit per device: the attribute belongs to the device
+    if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_kernel<R, Arith>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured = true;
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
     }
     const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
     hipLaunchKernelGGL((interseq_pair_kernel<R, Arith>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
@@ -795,6 +808,207 @@ static hipError_t launchPairFlavour(const InterseqArgs& a, int rowsPerStrip, int
         case 48: return launchPairR<48, Arith>(a, computeUnits, stream);
         case 56: return launchPairR<56, Arith>(a, computeUnits, stream);
         case 64: return launchPairR<64, Arith>(a, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- single-strip Smith-Waterman on biased integer halves, column-shifted ---------
+// Third arithmetic for the pair-table kernel. A half holds the unsigned integer
+//     kBiasedZero + x + shift(j),      shift(j) = (j - j0) * ext,
+// for a true value x of column j, and is COMPARED as a half float: between 0x0400 (smallest
+// normal) and 0x7BFF (largest finite) the order of the bit patterns is the order of the
+// numbers, so v_pk_maximum3_f16 still folds two max per cell while every addition is a plain
+// 32-bit integer add over both halves at once: the pair table holds
+// (sB' << 16) + sA' as ONE signed integer, so the borrow of a negative low score is undone by
+// the carry of the sum as long as each half stays in [0, 65535]. The column shift makes
+// extending E free (the next column's shift absorbs the ext) and lets E and F open with the same
+// h - (open - ext); the Smith-Waterman floor becomes the column's own zero `fl`:
+//     h    = max3(Hdiag + s', E, F)                s' = s + ext (one column to the right)
+//     hmo  = h - (open - ext)
+//     E    = max3(E, hmo, fl + ext)                (already on the next column's scale)
+//     F    = max3(F, hmo, fl + ext) - ext
+// 3 integer adds + 3.5 max3 per cell pair instead of 4 packed half adds + 3.5 max3, and the exact
+// range grows from 2048 to kBiasedLimit. Measured mix: tools/ubench_mix.hip. Every kBiasedMaxShift
+// of accumulated shift the state is rebased (112 subtractions). A half that reaches 0x7C00
+// (inf / NaN patterns) makes the column maximum inf / NaN (maximum3 propagates NaN, payloads stay
+// below 0x8000), the running best is an INTEGER max of (column maximum - fl) and therefore ends
+// at or above kBiasedLimit: the lane is flagged and redone by the next rung.
+constexpr int kBiasedZero = 0x0800;      // pattern of a true 0 at shift 0; 0x0400 of room below
+constexpr int kBiasedGuard = 0x0400;     // how far a value may dip below the column's zero
+constexpr int kBiasedMaxShift = 4096;
+constexpr int kBiasedLimit = 0x7C00 - kBiasedZero - kBiasedMaxShift;  // 25600
+constexpr int kBiasedPadScore = -kBiasedGuard;  // padding symbol / padding rows (true value)
+static_assert(kBiasedLimit == kBiasedScoreLimit && kBiasedPadScore == kBiasedPad, "common.h mirrors these");
+static_assert(kBiasedMaxMagnitude <= kBiasedGuard && 5 * kBiasedMaxExt <= kBiasedMaxShift, "guard band");
+
+static __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+    u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+// the same signed value in both halves, as one integer (see above)
+static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)(v * 0x00010001); }
+
+template <int R>
+__global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kernel(InterseqArgs a) {
+    constexpr int SLOTS = PairLayout<R>::kRowSlots;
+    constexpr int NB4 = R / 4;
+    extern __shared__ uint4 pairs[];
+
+    const int lane = threadIdx.x & 63;
+    const int nSym = a.nSymbols;
+    const int ext = a.gapExt;
+    const uint32_t ext2 = both(ext), openMinusExt2 = both(a.gapOpen - ext), zero2 = both(kBiasedZero);
+
+    // build the table: one thread per (pair row, query row); profile = true scores as int16
+    {
+        const int16_t* gp = a.profile;
+        uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
+        const int total = nSym * nSym * R;
+        for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
+            const int row = idx / R, r = idx - row * R;
+            const int tA = row / nSym, tB = row - tA * nSym;
+            const int sA = gp[tA * a.qPad + r] + ext, sB = gp[tB * a.qPad + r] + ext;
+            pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
+        }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6;
+    constexpr int kTier[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
+    const int tier = kTier[wave & 3][wave >> 2];
+    const int firstDynamic = kPairWaves * gridDim.x;
+    bool firstRound = true;
+    for (;;) {
+        int g;
+        if (firstRound) {
+            g = tier * gridDim.x + ((tier & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x);
+            firstRound = false;
+            if (g >= a.nGroups) continue;
+            g += a.groupBase;
+        } else {
+            g = 0;
+            if (lane == 0) g = atomicAdd(a.workCounter, 1);
+            g = __builtin_amdgcn_readfirstlane(g) + firstDynamic;
+            if (g >= a.nGroups) break;
+            g += a.groupBase;
+        }
+        const uint2* pack = a.pack + a.groupOff[g];
+        const int nChunks = a.groupChunks[g];
+        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        uint32_t best = 0u;                 // true values, integer order
+        uint32_t fl = zero2 - ext2;         // zero of column -1
+        int shift = -ext;                   // fl = zero2 + both(shift); wave-uniform
+        uint32_t H[R], E[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            H[r] = fl;                      // H[r][-1] = 0 on column -1's scale
+            E[r] = zero2;                   // E[r][0]  = 0 on column 0's scale
+        }
+        uint2 cur = pack[lane];
+        for (int c = 0; c < nChunks; ++c) {
+            uint2 nxt = {0, 0};
+            if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+            uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+            for (int cc = 0; cc < 4; ++cc) {
+                const uint32_t tA = ra & 0xffu, tB = rb & 0xffu;
+                ra >>= 8;
+                rb >>= 8;
+                const uint4* prow = pairs + (tA * nSym + tB) * SLOTS;
+                uint4 v[NB4];
+                v[0] = prow[0];
+                auto score = [&](int r) -> uint32_t {
+                    const uint4 x = v[r >> 2];
+                    const int k = r & 3;
+                    return k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                };
+                uint32_t dsum = fl + score(0);      // H[-1][j-1] = 0 on the previous column's scale
+                fl += ext2;                         // this column's zero
+                uint32_t fl1 = fl + ext2;           // the next column's
+                // (wave-uniform, so hipcc would keep it in an SGPR: v_pk_maximum3_f16 with a scalar
+                // operand issues ~10 % slower, profiles/r01_valu_issue_rates.txt)
+                asm volatile("" : "+v"(fl1));
+                uint32_t f = fl, cm = fl, held = fl;
+#pragma unroll
+                for (int r4 = 0; r4 < NB4; ++r4) {
+                    if (r4 + 1 < NB4) v[r4 + 1] = prow[r4 + 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = r4 * 4 + k;
+                        uint32_t dnext = 0;
+                        if (r + 1 < R) dnext = H[r] + score(r + 1);
+                        const uint32_t h = pk_max3_f16(dsum, E[r], f);
+                        if (r & 1) cm = pk_max3_f16(cm, held, h);
+                        else held = h;
+                        const uint32_t hmo = h - openMinusExt2;
+                        E[r] = pk_max3_f16(E[r], hmo, fl1);
+                        if (r + 1 < R) f = pk_max3_f16(f, hmo, fl1) - ext2;
+                        H[r] = h;
+                        dsum = dnext;
+                    }
+                    if (r4 & 1) asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                }
+                if (R & 1) cm = pk_max3_f16(cm, held, held);
+                best = pk_max_u16(best, cm - fl);
+            }
+            cur = nxt;
+            shift += 4 * ext;
+            if (shift + 4 * ext > kBiasedMaxShift) {
+                // rebase: H is on the last column's scale, E on the next one's, both relative to fl
+                const uint32_t d = both(shift);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    H[r] -= d;
+                    E[r] -= d;
+                }
+                fl -= d;
+                shift = 0;
+            }
+        }
+        const int lo = (int)(best & 0xffffu), hi = (int)(best >> 16);
+        const size_t base = (size_t)g * kGroupTargets;
+        a.score[base + lane] = lo;
+        a.score[base + kLanes + lane] = hi;
+        if (a.overflow) {
+            a.overflow[base + lane] = lo >= kBiasedLimit;
+            a.overflow[base + kLanes + lane] = hi >= kBiasedLimit;
+        }
+    }
+}
+
+template <int R>
+static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols);
+    static uint64_t configured = 0;  // one bit per device; setting the attribute twice is harmless
+    if (firstUseOnThisDevice(&configured)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_biased_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
+    }
+    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
+    hipLaunchKernelGGL((interseq_pair_biased_kernel<R>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    return hipGetLastError();
+}
+
+// (a template only so that translation units that do not use it do not instantiate the kernels)
+template <int kUnused = 0>
+static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    if (a.nStrips != 1) return hipErrorInvalidValue;
+    switch (rowsPerStrip) {
+        case 8: return launchPairBiasedR<8>(a, computeUnits, stream);
+        case 16: return launchPairBiasedR<16>(a, computeUnits, stream);
+        case 24: return launchPairBiasedR<24>(a, computeUnits, stream);
+        case 32: return launchPairBiasedR<32>(a, computeUnits, stream);
+        case 40: return launchPairBiasedR<40>(a, computeUnits, stream);
+        case 48: return launchPairBiasedR<48>(a, computeUnits, stream);
+        case 56: return launchPairBiasedR<56>(a, computeUnits, stream);
+        case 64: return launchPairBiasedR<64>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

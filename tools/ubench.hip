@@ -74,6 +74,33 @@ DEFINE(add_u32_e64, "v_add_u32_e64 %0, %0, %1")
 DEFINE(max_i32_e64, "v_max_i32_e64 %0, %0, %1")
 DEFINE(sat_pk_sdwa_add_u8, "v_add_u16_sdwa %0, %0, %1 clamp dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0")
 
+
+// ---- mixed streams: does a full-rate op stay full-rate next to half-rate ones? ----
+#define DEFINE2(NAME, ASMA, ASMB, NA, NB)                                                  \
+__global__ void k_##NAME(unsigned* out, unsigned seed) {                                   \
+    unsigned a[8], d[8], b = seed + threadIdx.x, c = seed * 3 + 1;                         \
+    for (int i = 0; i < 8; ++i) { a[i] = seed + i * 77 + threadIdx.x; d[i] = a[i] * 3; }   \
+    for (int it = 0; it < ITERS; ++it) {                                                   \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                    \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                \
+                if (i % ((NA) + (NB)) < (NA)) asm volatile(ASMA : "+v"(a[i]) : "v"(b), "v"(c)); \
+                else asm volatile(ASMB : "+v"(d[i]) : "v"(b), "v"(c));                     \
+            }                                                                              \
+        }                                                                                  \
+    }                                                                                      \
+    unsigned r = 0;                                                                        \
+    for (int i = 0; i < 8; ++i) r ^= a[i] ^ d[i];                                          \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                        \
+}
+DEFINE2(alt_add_max3, "v_add_u32 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %2", 1, 1)
+DEFINE2(alt_add_add, "v_add_u32 %0, %0, %1", "v_sub_u32 %0, %0, %1", 1, 1)
+DEFINE2(alt_3add_1max3, "v_add_u32 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %2", 3, 1)
+DEFINE2(alt_1add_3max3, "v_add_u32 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %2", 1, 3)
+DEFINE2(alt_add_pkmax, "v_add_u32 %0, %0, %1", "v_pk_max_i16 %0, %0, %1", 1, 1)
+DEFINE2(alt_add_max3_2src, "v_add_u32 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %1", 1, 1)
+DEFINE2(alt_maxu16_max3, "v_max_u16 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %2", 1, 1)
+DEFINE2(alt_pkaddu16_max3, "v_pk_add_u16 %0, %0, %1", "v_pk_maximum3_f16 %0, %0, %1, %2", 1, 1)
+
 struct Entry { const char* name; void (*fn)(unsigned*, unsigned); int perAsm; };
 #define E(NAME, N) {#NAME, k_##NAME, N}
 
@@ -88,7 +115,7 @@ int main(int argc, char** argv) {
         E(max_i32,1), E(max3_i32,1), E(add_u32,1), E(sub_u32_clamp,1), E(add3_u32,1), E(pk_maximum3_f16,1), E(pk_add_f16,1),
         E(pk_max_f16,1), E(max3_i16,1), E(max_i16,1), E(max_u16_sdwa,1), E(dot4_i32_i8,1), E(mov_b32,1), E(lshl_or_b32,1),
         E(and_or_b32,1), E(fma_f32,1), E(pk_fma_f16,1), E(mad_i32_i24,1), E(pk_mad_i16,1), E(mix_pk_and_i32,2), E(med3_i32,1),
-        E(maximum3_f32,1), E(pk_max_i16_sgpr,1), E(cndmask,1), E(min_u32,1), E(max_u32,1), E(sub_u32,1), E(and_b32,1), E(xor_b32,1), E(lshlrev_b32,1), E(max_f32,1), E(add_f32,1), E(max_u16,1), E(pk_min_i16,1), E(add_u16,1), E(fmac_f32,1), E(add_u32_e64,1), E(max_i32_e64,1), E(sat_pk_sdwa_add_u8,1) };
+        E(maximum3_f32,1), E(pk_max_i16_sgpr,1), E(cndmask,1), E(min_u32,1), E(max_u32,1), E(sub_u32,1), E(and_b32,1), E(xor_b32,1), E(lshlrev_b32,1), E(max_f32,1), E(add_f32,1), E(max_u16,1), E(pk_min_i16,1), E(add_u16,1), E(fmac_f32,1), E(add_u32_e64,1), E(max_i32_e64,1), E(sat_pk_sdwa_add_u8,1), E(alt_add_max3,1), E(alt_add_add,1), E(alt_3add_1max3,1), E(alt_1add_3max3,1), E(alt_add_pkmax,1), E(alt_add_max3_2src,1), E(alt_maxu16_max3,1), E(alt_pkaddu16_max3,1) };
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(k_add_u32, dim3(blocks), dim3(256), 0, 0, out, 1u);
     CHECK(hipDeviceSynchronize());
