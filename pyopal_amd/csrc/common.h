@@ -41,6 +41,7 @@ struct InterseqArgs {
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
     int priorityChunks;        // groups with more chunks than this raise their wave priority
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
+    int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -170,7 +171,10 @@ constexpr int kBiasedMaxExt = 512;
 constexpr int kBiasedPad = -1024;          // = kBiasedPadScore: padding symbol / rows in the profile
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream);
-hipError_t launchInterseqPairSwBiased(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);

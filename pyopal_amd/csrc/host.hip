@@ -1021,9 +1021,20 @@ struct Search {
                 int pairUnits = db->computeUnits;
                 if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
+                // groups of similar length: every SIMD takes the same share of them (interseq_impl.h)
+                {
+                    const int blocks = std::max(1, std::min(pairUnits, (ia.nGroups + 11) / 12));
+                    const int longest = view->groupChunksHost[firstGroup];
+                    const int shortest = view->groupChunksHost[view->nGroups - 1];
+                    const char* tt = getenv("MIOPAL_TAIL_THROTTLE");
+                    const bool uniform = (int64_t)shortest * 5 >= (int64_t)longest * 4;
+                    ia.tailThrottle = (tt ? tt[0] == '1' : uniform) ? (ia.nGroups + blocks * 4 - 1) / (blocks * 4) : 0;
+                }
                 const PairFlavour pf = biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
                 g_lastRouting[1] = 2 + (int)pf;
-                const hipError_t pe = launchInterseqPair(ia, rows, pf, pairUnits, stream);
+                // the biased kernel exists for every even number of rows: no padding rows to 8
+                const int pairRows = biased ? std::max(2, (Q + 1) / 2 * 2) : rows;
+                const hipError_t pe = launchInterseqPair(ia, pairRows, pf, pairUnits, stream);
                 if (pe != hipSuccess) {
                     // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant (the
                     // biased profile is a plain int16 profile whose padding score, -1024, cannot raise

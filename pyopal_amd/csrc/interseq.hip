@@ -27,7 +27,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
 }
 
 bool interseqPairFits(int rowsPerStrip, int nSymbols) {
-    const size_t bytes = (size_t)nSymbols * nSymbols * (size_t)((rowsPerStrip / 4) | 1) * 16;
+    const size_t bytes = (size_t)nSymbols * nSymbols * (size_t)(((rowsPerStrip + 3) / 4) | 1) * 16;
     return bytes <= 158 * 1024;  // leaves the runtime a little of the 160 KB
 }
 
@@ -35,7 +35,13 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
                               hipStream_t stream) {
     if (a.nGroups <= 0) return hipSuccess;
     switch (flavour) {
-        case kPairSwBiased: return launchInterseqPairSwBiased(a, rowsPerStrip, computeUnits, stream);
+        case kPairSwBiased:
+            // any even number of rows
+            if (rowsPerStrip < 2 || rowsPerStrip > 64 || (rowsPerStrip & 1)) return hipErrorInvalidValue;
+            if (rowsPerStrip < 18) return launchInterseqPairSwBiasedA(a, rowsPerStrip, computeUnits, stream);
+            if (rowsPerStrip < 34) return launchInterseqPairSwBiasedB(a, rowsPerStrip, computeUnits, stream);
+            if (rowsPerStrip < 50) return launchInterseqPairSwBiasedC(a, rowsPerStrip, computeUnits, stream);
+            return launchInterseqPairSwBiasedD(a, rowsPerStrip, computeUnits, stream);
         case kPairSwHalf: return launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream);
         case kPairSwInt16: return launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
     }

@@ -645,7 +645,7 @@ constexpr int kPairWaves = 12;  // 3 per SIMD at <= 168 VGPRs
 
 template <int R>
 struct PairLayout {
-    static constexpr int kRowSlots = (R / 4) | 1;  // 16-byte slots per row, odd: rows start on different slots
+    static constexpr int kRowSlots = ((R + 3) / 4) | 1;  // 16-byte slots per row, odd: rows start on different slots
     static __host__ __device__ constexpr size_t bytes(int nSymbols) {
         return (size_t)nSymbols * nSymbols * kRowSlots * 16;
     }
@@ -851,7 +851,7 @@ static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)(v * 0
 template <int R>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kernel(InterseqArgs a) {
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
-    constexpr int NB4 = R / 4;
+    constexpr int NB4 = (R + 3) / 4;   // R need not be a multiple of 4: the last read is partly used
     extern __shared__ uint4 pairs[];
 
     const int lane = threadIdx.x & 63;
@@ -871,23 +871,39 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
             pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
         }
     }
+    // groups handed to the wavefronts of each SIMD (end game below): 16 bytes behind the table
+    int* simdTaken = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);
+    if (threadIdx.x < 4) simdTaken[threadIdx.x] = 0;
     __syncthreads();
 
     const int wave = threadIdx.x >> 6;
     constexpr int kTier[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
     const int tier = kTier[wave & 3][wave >> 2];
     const int firstDynamic = kPairWaves * gridDim.x;
+    // HW_REG_HW_ID (4), SIMD_ID = bits 5:4
+    const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
     bool firstRound = true;
     for (;;) {
         int g;
         if (firstRound) {
             g = tier * gridDim.x + ((tier & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x);
             firstRound = false;
+            if (lane == 0 && a.tailThrottle > 0) atomicAdd(&simdTaken[simd], 1);
             if (g >= a.nGroups) continue;
             g += a.groupBase;
         } else {
             g = 0;
-            if (lane == 0) g = atomicAdd(a.workCounter, 1);
+            if (lane == 0) {
+                // Groups of similar length (a.tailThrottle = groups per SIMD, rounded up; else 0): a
+                // SIMD that takes one group more than its share works a whole extra round while its
+                // neighbours idle, so every SIMD stops at its share - counted in LDS per hardware
+                // SIMD - and the last round runs two wavefronts (or one) per SIMD, each faster for it.
+                // Shares add up to at least the number of groups, and a SIMD below its share keeps
+                // asking, so every group is taken.
+                bool take = true;
+                if (a.tailThrottle > 0) take = atomicAdd(&simdTaken[simd], 1) < a.tailThrottle;
+                g = take ? atomicAdd(a.workCounter, 1) : INT32_MAX - firstDynamic;
+            }
             g = __builtin_amdgcn_readfirstlane(g) + firstDynamic;
             if (g >= a.nGroups) break;
             g += a.groupBase;
@@ -915,7 +931,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                 const uint32_t tA = ra & 0xffu, tB = rb & 0xffu;
                 ra >>= 8;
                 rb >>= 8;
-                const uint4* prow = pairs + (tA * nSym + tB) * SLOTS;
+                // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
+                const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
+                const uint4* prow = reinterpret_cast<const uint4*>(
+                    reinterpret_cast<const char*>(pairs) + __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
                 uint4 v[NB4];
                 v[0] = prow[0];
                 auto score = [&](int r) -> uint32_t {
@@ -936,6 +955,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = r4 * 4 + k;
+                        if (r >= R) continue;
                         uint32_t dnext = 0;
                         if (r + 1 < R) dnext = H[r] + score(r + 1);
                         const uint32_t h = pk_max3_f16(dsum, E[r], f);
@@ -979,7 +999,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
 
 template <int R>
 static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    const size_t lds = PairLayout<R>::bytes(a.nSymbols);
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + per-SIMD counters
     static uint64_t configured = 0;  // one bit per device; setting the attribute twice is harmless
     if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_biased_kernel<R>),
@@ -996,26 +1016,27 @@ static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hip
     return hipGetLastError();
 }
 
-// (a template only so that translation units that do not use it do not instantiate the kernels)
-template <int kUnused = 0>
+template <int kLo>
 static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
     if (a.nStrips != 1) return hipErrorInvalidValue;
-    switch (rowsPerStrip) {
-        case 8: return launchPairBiasedR<8>(a, computeUnits, stream);
-        case 16: return launchPairBiasedR<16>(a, computeUnits, stream);
-        case 24: return launchPairBiasedR<24>(a, computeUnits, stream);
-        case 32: return launchPairBiasedR<32>(a, computeUnits, stream);
-        case 40: return launchPairBiasedR<40>(a, computeUnits, stream);
-        case 48: return launchPairBiasedR<48>(a, computeUnits, stream);
-        case 56: return launchPairBiasedR<56>(a, computeUnits, stream);
-        case 64: return launchPairBiasedR<64>(a, computeUnits, stream);
+    // rows: any even number in [kLo, kLo + 14]; the translation units interseq_swb16_{a,b,c,d}.hip
+    // share the 32 instantiations
+    switch (rowsPerStrip - kLo) {
+        case 0: return launchPairBiasedR<kLo>(a, computeUnits, stream);
+        case 2: return launchPairBiasedR<kLo + 2>(a, computeUnits, stream);
+        case 4: return launchPairBiasedR<kLo + 4>(a, computeUnits, stream);
+        case 6: return launchPairBiasedR<kLo + 6>(a, computeUnits, stream);
+        case 8: return launchPairBiasedR<kLo + 8>(a, computeUnits, stream);
+        case 10: return launchPairBiasedR<kLo + 10>(a, computeUnits, stream);
+        case 12: return launchPairBiasedR<kLo + 12>(a, computeUnits, stream);
+        case 14: return launchPairBiasedR<kLo + 14>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }
 
 // Bytes of LDS the pair table needs for this strip height (host-side sizing).
 static inline size_t pairTableBytes(int rowsPerStrip, int nSymbols) {
-    return (size_t)nSymbols * nSymbols * (size_t)((rowsPerStrip / 4) | 1) * 16;
+    return (size_t)nSymbols * nSymbols * (size_t)(((rowsPerStrip + 3) / 4) | 1) * 16;
 }
 
 }  // namespace miopal

@@ -22,9 +22,9 @@ stream = torch.cuda.current_stream().cuda_stream
 db.search_device_scores(q, m, out.data_ptr(), stream, 3, 1, algo); torch.cuda.synchronize(); t2 = time.time()
 print(f"create {t1-t0:.3f}s first search (incl. view build) {t2-t1:.3f}s")
 db.set_profiling(True)
-for it in range(3):
+for it in range(int(os.environ.get("QB_ROUNDS", "6"))):
     torch.cuda.synchronize(); t = time.time()
-    K = 5
+    K = 10
     for _ in range(K):
         db.search_device_scores(q, m, out.data_ptr(), stream, 3, 1, algo)
     torch.cuda.synchronize(); dt = (time.time() - t) / K
