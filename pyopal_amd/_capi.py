@@ -11,7 +11,8 @@ import typing
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiopal.so")
+# MIOPAL_LIBRARY: another build of the same library (A/B timing of kernel variants, tools/ab_build.sh)
+LIB_PATH = os.environ.get("MIOPAL_LIBRARY") or os.path.join(_HERE, "libmiopal.so")
 
 OPAL_ERR_OVERFLOW = 1
 OPAL_ERR_NO_SIMD_SUPPORT = 2

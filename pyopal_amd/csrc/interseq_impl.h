@@ -922,21 +922,46 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
             E[r] = zero2;                   // E[r][0]  = 0 on column 0's scale
         }
         uint2 cur = pack[lane];
+        // LDS row of a residue pair (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
+        auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
+            const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
+            return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
+                                                  __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
+        };
+        // The first two 4-row blocks of a column are fetched while the column before it is still
+        // being computed, the others two blocks ahead of their use: an LDS read waits behind the
+        // other eleven wavefronts' (bank-conflicted) reads, and a column that starts by waiting
+        // for its first scores leaves the SIMD to two wavefronts.
+#ifndef MIOPAL_PAIR_AHEAD
+#define MIOPAL_PAIR_AHEAD 3
+#endif
+#ifndef MIOPAL_PAIR_XCOL
+#define MIOPAL_PAIR_XCOL 1
+#endif
+        // (three blocks ahead is the best of 1..3 on cfg2; 64 rows leave registers for two)
+        constexpr int kWant = R > 60 ? 2 : MIOPAL_PAIR_AHEAD;
+        constexpr int kAhead = NB4 > kWant ? kWant : 1;
+        constexpr bool kAcross = MIOPAL_PAIR_XCOL != 0;
+        const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
+        uint4 vn[kAhead];
+        if (kAcross) {
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+        }
         for (int c = 0; c < nChunks; ++c) {
             uint2 nxt = {0, 0};
             if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
             uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
             for (int cc = 0; cc < 4; ++cc) {
-                const uint32_t tA = ra & 0xffu, tB = rb & 0xffu;
-                ra >>= 8;
-                rb >>= 8;
-                // (24-bit multiplies: v_mul_lo_u32 is a quarter-rate instruction)
-                const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
-                const uint4* prow = reinterpret_cast<const uint4*>(
-                    reinterpret_cast<const char*>(pairs) + __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
+                const uint4* prow = prowNext;
                 uint4 v[NB4];
-                v[0] = prow[0];
+#pragma unroll
+                for (int k = 0; k < kAhead; ++k) v[k] = kAcross ? vn[k] : prow[k];
+                // the column after this one (past the group's end: row 0, never used)
+                ra = cc < 3 ? ra >> 8 : nxt.x;
+                rb = cc < 3 ? rb >> 8 : nxt.y;
+                prowNext = rowOf(ra & 0xffu, rb & 0xffu);
                 auto score = [&](int r) -> uint32_t {
                     const uint4 x = v[r >> 2];
                     const int k = r & 3;
@@ -951,7 +976,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                 uint32_t f = fl, cm = fl, held = fl;
 #pragma unroll
                 for (int r4 = 0; r4 < NB4; ++r4) {
-                    if (r4 + 1 < NB4) v[r4 + 1] = prow[r4 + 1];
+                    if (r4 + kAhead < NB4) v[r4 + kAhead] = prow[r4 + kAhead];
+                    if (kAcross && r4 == (NB4 > 3 ? NB4 - 3 : 0)) {
+#pragma unroll
+                        for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int r = r4 * 4 + k;
@@ -967,7 +996,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                         H[r] = h;
                         dsum = dnext;
                     }
-                    if (r4 & 1) asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                    // pins the schedule: hipcc would otherwise hoist every ds_read to the column's top
+                    asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
                 }
                 if (R & 1) cm = pk_max3_f16(cm, held, held);
                 best = pk_max_u16(best, cm - fl);

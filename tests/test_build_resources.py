@@ -1,0 +1,53 @@
+"""The compiler's resource remarks of the last in-tree build (pyopal_amd/csrc/*.rpt, written by
+the Makefile): the lane-per-target kernels keep their whole DP column in registers, so a spill
+(a change that pushes one instantiation over the budget of its occupancy) costs a factor, not
+per cents - it must fail here, not show up as a slow bench."""
+import glob
+import os
+import re
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pyopal_amd", "csrc")
+
+
+def kernels():
+    out = {}
+    for path in glob.glob(os.path.join(CSRC, "*.rpt")):
+        name = None
+        for line in open(path, errors="replace"):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                name = m.group(1)
+                out[name] = {"file": os.path.basename(path)}
+                continue
+            m = re.search(r"remark:\s+(VGPRs|VGPRs Spill|SGPRs Spill|Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]): (\d+)", line)
+            if m and name:
+                out[name][m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_hot_kernels_do_not_spill():
+    ks = kernels()
+    if not ks:
+        pytest.skip("no resource remarks: build with make -C pyopal_amd/csrc")
+    hot = {n: k for n, k in ks.items() if "interseq" in n or "perpair" in n}
+    assert len(hot) >= 40, sorted(hot)
+    bad = {n: k for n, k in hot.items() if k.get("VGPRs Spill", 0) or k.get("ScratchSize [bytes/lane]", 0)}
+    # Known: the 8-wavefront, 64-row instantiations of the general kernel (512 threads: 256 VGPRs) park
+    # a few scalars in scratch outside the cell loop (<= 128 bytes per lane); nothing else may.
+    for name in list(bad):
+        if "interseq_kernelILi64E" in name and "ELi8E" in name and bad[name]["ScratchSize [bytes/lane]"] <= 128:
+            del bad[name]
+    assert not bad, bad
+
+
+def test_pair_table_kernels_keep_three_wavefronts_per_simd():
+    ks = kernels()
+    if not ks:
+        pytest.skip("no resource remarks: build with make -C pyopal_amd/csrc")
+    pair = {n: k for n, k in ks.items() if "interseq_pair" in n}
+    assert pair
+    # kPairWaves = 12 wavefronts per workgroup, one workgroup per CU: 3 per SIMD, <= 168 VGPRs
+    low = {n: k for n, k in pair.items() if k.get("Occupancy [waves/SIMD]", 0) < 3}
+    assert not low, low
