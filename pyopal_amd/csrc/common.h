@@ -169,12 +169,22 @@ constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above
 constexpr int kBiasedMaxMagnitude = 1024;  // |score|, open - ext, ext - open
 constexpr int kBiasedMaxExt = 512;
 constexpr int kBiasedPad = -1024;          // = kBiasedPadScore: padding symbol / rows in the profile
+// the biased flavour with end locations (scaled by 2^bits, bits = 4 / 5 / 6 for <= 16 / 32 / 64 rows)
+constexpr int kLocZeroPattern = 0x0C00;
+constexpr int kLocGuardBand = 0x0800;      // |score| << bits, (open - ext) << bits, (ext - open) << bits
+constexpr int kLocMaxShift = 4096;         // 5 * (ext << bits) must fit
+inline int locRowBitsHost(int rows) { return rows <= 16 ? 4 : rows <= 32 ? 5 : 6; }
+inline int locLimitHost(int rows) { return (0x7C00 - kLocZeroPattern - kLocMaxShift) >> locRowBitsHost(rows); }
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
-                              hipStream_t stream);
+                              hipStream_t stream, bool locate = false);
 hipError_t launchInterseqPairSwBiasedA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedLocC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwBiasedLocD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwHalf(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwInt16(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqSwHalf(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);

@@ -887,14 +887,21 @@ struct Search {
             const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
             // one strip + Smith-Waterman scores: the pair-indexed LDS profile saves the v_perm per cell
             const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
-            const bool usePair = sw && !locate && nStrips == 1 && !(noPair && noPair[0] == '1') &&
-                                 interseqPairFits(rows, nSym);
             // first rung of the pair-table kernel: biased integer halves (exact below 25600,
-            // interseq_impl.h) when the scores and gap costs leave its guard band alone
-            const bool biased = usePair && useHalf && maxScore <= kBiasedMaxMagnitude &&
-                                minScore >= -kBiasedMaxMagnitude && ext <= kBiasedMaxExt &&
-                                open - ext <= kBiasedMaxMagnitude && ext - open <= kBiasedMaxMagnitude &&
-                                !getenv("MIOPAL_NO_BIASED");
+            // interseq_impl.h) when the scores and gap costs leave its guard band alone: a step up
+            // (score + ext, or ext - open) of at most 0x0400 so that a finite half cannot jump over
+            // the NaN patterns, a step down (score + ext, open - ext) within the room below zero.
+            // With end locations every value is scaled by 2^bits (row keys in the low bits).
+            const int pairRows = std::max(2, (Q + 1) / 2 * 2);
+            const int bits = locate ? locRowBitsHost(pairRows) : 0;
+            const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
+            const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
+            const bool biasedFits = nStrips == 1 && useHalf && !getenv("MIOPAL_NO_BIASED") &&
+                                    (up << bits) <= 0x0400 && (down << bits) <= (locate ? kLocGuardBand : kBiasedMaxMagnitude) &&
+                                    5 * ((int64_t)ext << bits) <= kLocMaxShift && minScore > kBiasedPad;
+            const bool usePair = sw && nStrips == 1 && !(noPair && noPair[0] == '1') &&
+                                 interseqPairFits(locate ? pairRows : rows, nSym) && (!locate || biasedFits);
+            const bool biased = usePair && biasedFits;
             // Half floats turn a sum above 65504 into +inf, and inf + (-inf padding) into NaN, which
             // the flag `best >= 2048` would miss (NaN converts to 0): only matrices whose best
             // possible score stays finite take the half-float rung.
@@ -963,7 +970,7 @@ struct Search {
             RC_TRY(ws->stageUpload(pp, prof.data(), prof.size() * sizeof(prof[0]), stream));
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
             const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
-            const int64_t limit = biased ? kBiasedScoreLimit : halfFloat ? 2048 : 32767;
+            const int64_t limit = biased ? (locate ? locLimitHost(pairRows) : kBiasedScoreLimit) : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
@@ -1033,8 +1040,7 @@ struct Search {
                 const PairFlavour pf = biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
                 g_lastRouting[1] = 2 + (int)pf;
                 // the biased kernel exists for every even number of rows: no padding rows to 8
-                const int pairRows = biased ? std::max(2, (Q + 1) / 2 * 2) : rows;
-                const hipError_t pe = launchInterseqPair(ia, pairRows, pf, pairUnits, stream);
+                const hipError_t pe = launchInterseqPair(ia, biased ? pairRows : rows, pf, pairUnits, stream, locate);
                 if (pe != hipSuccess) {
                     // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant (the
                     // biased profile is a plain int16 profile whose padding score, -1024, cannot raise

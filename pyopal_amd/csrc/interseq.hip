@@ -32,12 +32,19 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols) {
 }
 
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool locate) {
     if (a.nGroups <= 0) return hipSuccess;
+    if (locate && flavour != kPairSwBiased) return hipErrorInvalidValue;
     switch (flavour) {
         case kPairSwBiased:
             // any even number of rows
             if (rowsPerStrip < 2 || rowsPerStrip > 64 || (rowsPerStrip & 1)) return hipErrorInvalidValue;
+            if (locate) {
+                if (rowsPerStrip < 18) return launchInterseqPairSwBiasedLocA(a, rowsPerStrip, computeUnits, stream);
+                if (rowsPerStrip < 34) return launchInterseqPairSwBiasedLocB(a, rowsPerStrip, computeUnits, stream);
+                if (rowsPerStrip < 50) return launchInterseqPairSwBiasedLocC(a, rowsPerStrip, computeUnits, stream);
+                return launchInterseqPairSwBiasedLocD(a, rowsPerStrip, computeUnits, stream);
+            }
             if (rowsPerStrip < 18) return launchInterseqPairSwBiasedA(a, rowsPerStrip, computeUnits, stream);
             if (rowsPerStrip < 34) return launchInterseqPairSwBiasedB(a, rowsPerStrip, computeUnits, stream);
             if (rowsPerStrip < 50) return launchInterseqPairSwBiasedC(a, rowsPerStrip, computeUnits, stream);

@@ -841,6 +841,19 @@ constexpr int kBiasedPadScore = -kBiasedGuard;  // padding symbol / padding rows
 static_assert(kBiasedLimit == kBiasedScoreLimit && kBiasedPadScore == kBiasedPad, "common.h mirrors these");
 static_assert(kBiasedMaxMagnitude <= kBiasedGuard && 5 * kBiasedMaxExt <= kBiasedMaxShift, "guard band");
 
+// End locations (LOC): every value is scaled by 2^kBits (kBits = 4, 5 or 6: enough for the strip's
+// rows), so the low bits of a cell are free, and the key  h + (2^kBits - 1 - row)  is folded instead
+// of h: the column maximum then carries the FIRST row that holds it, for one more integer add per
+// cell pair, and the running best (an integer max against best | rowmask, i.e. strictly greater
+// scores only) carries the row of the first maximum in column-major order. No row scan. The exact
+// range shrinks to kLocLimit(kBits) - 384 for 64 rows, above what a 64-residue query can score with
+// the usual protein matrices short of near-identity; flagged lanes take the next rung as always.
+constexpr int kLocZero = 0x0C00;         // 0x0800 of room below: scores down to -32 at 6 bits
+constexpr int kLocGuard = 0x0800;
+static_assert(kLocGuard == kLocGuardBand && kBiasedMaxShift == kLocMaxShift && kLocZero == kLocZeroPattern, "common.h mirrors these");
+__host__ __device__ constexpr int locRowBits(int rows) { return rows <= 16 ? 4 : rows <= 32 ? 5 : 6; }
+__host__ __device__ constexpr int locLimit(int bits) { return (0x7C00 - kLocZero - kBiasedMaxShift) >> bits; }
+
 static __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
     return __builtin_bit_cast(uint32_t, r);
@@ -848,16 +861,19 @@ static __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 // the same signed value in both halves, as one integer (see above)
 static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)(v * 0x00010001); }
 
-template <int R>
+template <int R, bool LOC>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kernel(InterseqArgs a) {
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
     constexpr int NB4 = (R + 3) / 4;   // R need not be a multiple of 4: the last read is partly used
+    constexpr int kBits = LOC ? locRowBits(R) : 0;
+    constexpr int kRowMask = (1 << kBits) - 1;
     extern __shared__ uint4 pairs[];
 
     const int lane = threadIdx.x & 63;
     const int nSym = a.nSymbols;
-    const int ext = a.gapExt;
-    const uint32_t ext2 = both(ext), openMinusExt2 = both(a.gapOpen - ext), zero2 = both(kBiasedZero);
+    const int ext = a.gapExt << kBits;   // pattern units
+    const uint32_t ext2 = both(ext), openMinusExt2 = both((a.gapOpen << kBits) - ext);
+    const uint32_t zero2 = both(LOC ? kLocZero : kBiasedZero);
 
     // build the table: one thread per (pair row, query row); profile = true scores as int16
     {
@@ -867,7 +883,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
         for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
             const int row = idx / R, r = idx - row * R;
             const int tA = row / nSym, tB = row - tA * nSym;
-            const int sA = gp[tA * a.qPad + r] + ext, sB = gp[tB * a.qPad + r] + ext;
+            // (padding symbol / padding rows: as far below the column's zero as the guard band allows)
+            constexpr int kPadPattern = LOC ? -kLocGuard : kBiasedPadScore;
+            const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
+            const int sA = (vA == kBiasedPadScore ? kPadPattern : vA << kBits) + ext;
+            const int sB = (vB == kBiasedPadScore ? kPadPattern : vB << kBits) + ext;
             pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
         }
     }
@@ -912,7 +932,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
         const int nChunks = a.groupChunks[g];
         if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
-        uint32_t best = 0u;                 // true values, integer order
+        uint32_t best = 0u;                 // true values (LOC: keys), integer order
+        int colA = -1, colB = -1;           // LOC: column of the first maximum of each half
         uint32_t fl = zero2 - ext2;         // zero of column -1
         int shift = -ext;                   // fl = zero2 + both(shift); wave-uniform
         uint32_t H[R], E[R];
@@ -939,7 +960,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
 #define MIOPAL_PAIR_XCOL 1
 #endif
         // (three blocks ahead is the best of 1..3 on cfg2; 64 rows leave registers for two)
-        constexpr int kWant = R > 60 ? 2 : MIOPAL_PAIR_AHEAD;
+        constexpr int kWant = LOC ? (R > 62 ? 1 : R > 58 ? 2 : MIOPAL_PAIR_AHEAD) : (R > 60 ? 2 : MIOPAL_PAIR_AHEAD);
         constexpr int kAhead = NB4 > kWant ? kWant : 1;
         constexpr bool kAcross = MIOPAL_PAIR_XCOL != 0;
         const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
@@ -988,8 +1009,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                         uint32_t dnext = 0;
                         if (r + 1 < R) dnext = H[r] + score(r + 1);
                         const uint32_t h = pk_max3_f16(dsum, E[r], f);
-                        if (r & 1) cm = pk_max3_f16(cm, held, h);
-                        else held = h;
+                        // what the column maximum folds: h, or h with the row in its free low bits
+                        const uint32_t hk = LOC ? h + both(kRowMask - r) : h;
+                        if (r & 1) cm = pk_max3_f16(cm, held, hk);
+                        else held = hk;
                         const uint32_t hmo = h - openMinusExt2;
                         E[r] = pk_max3_f16(E[r], hmo, fl1);
                         if (r + 1 < R) f = pk_max3_f16(f, hmo, fl1) - ext2;
@@ -1000,7 +1023,22 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                     asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
                 }
                 if (R & 1) cm = pk_max3_f16(cm, held, held);
-                best = pk_max_u16(best, cm - fl);
+                if constexpr (LOC) {
+                    // strictly greater scores only: compare against best with its row bits all set
+                    const uint32_t cand = cm - fl, thr = best | both(kRowMask);
+                    const uint32_t ch = pk_max_u16(thr, cand) ^ thr;   // nonzero half: new maximum
+                    const int j = c * 4 + cc;
+                    if (ch & 0xffffu) {
+                        best = (best & 0xffff0000u) | (cand & 0xffffu);
+                        colA = j;
+                    }
+                    if (ch >> 16) {
+                        best = (best & 0xffffu) | (cand & 0xffff0000u);
+                        colB = j;
+                    }
+                } else {
+                    best = pk_max_u16(best, cm - fl);
+                }
             }
             cur = nxt;
             shift += 4 * ext;
@@ -1016,23 +1054,30 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
                 shift = 0;
             }
         }
-        const int lo = (int)(best & 0xffffu), hi = (int)(best >> 16);
+        const int lo = (int)(best & 0xffffu) >> kBits, hi = (int)(best >> 16) >> kBits;
         const size_t base = (size_t)g * kGroupTargets;
         a.score[base + lane] = lo;
         a.score[base + kLanes + lane] = hi;
+        if constexpr (LOC) {
+            a.endI[base + lane] = colA < 0 ? -1 : kRowMask - (int)(best & kRowMask);
+            a.endI[base + kLanes + lane] = colB < 0 ? -1 : kRowMask - (int)((best >> 16) & kRowMask);
+            a.endJ[base + lane] = colA;
+            a.endJ[base + kLanes + lane] = colB;
+        }
         if (a.overflow) {
-            a.overflow[base + lane] = lo >= kBiasedLimit;
-            a.overflow[base + kLanes + lane] = hi >= kBiasedLimit;
+            constexpr int kLimit = LOC ? locLimit(kBits) : kBiasedLimit;
+            a.overflow[base + lane] = lo >= kLimit;
+            a.overflow[base + kLanes + lane] = hi >= kLimit;
         }
     }
 }
 
-template <int R>
+template <int R, bool LOC>
 static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
     const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + per-SIMD counters
     static uint64_t configured = 0;  // one bit per device; setting the attribute twice is harmless
     if (firstUseOnThisDevice(&configured)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_biased_kernel<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_biased_kernel<R, LOC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             int dev = 0;
@@ -1042,24 +1087,24 @@ static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hip
         }
     }
     const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
-    hipLaunchKernelGGL((interseq_pair_biased_kernel<R>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    hipLaunchKernelGGL((interseq_pair_biased_kernel<R, LOC>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
 
-template <int kLo>
+template <int kLo, bool LOC>
 static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
     if (a.nStrips != 1) return hipErrorInvalidValue;
     // rows: any even number in [kLo, kLo + 14]; the translation units interseq_swb16_{a,b,c,d}.hip
     // share the 32 instantiations
     switch (rowsPerStrip - kLo) {
-        case 0: return launchPairBiasedR<kLo>(a, computeUnits, stream);
-        case 2: return launchPairBiasedR<kLo + 2>(a, computeUnits, stream);
-        case 4: return launchPairBiasedR<kLo + 4>(a, computeUnits, stream);
-        case 6: return launchPairBiasedR<kLo + 6>(a, computeUnits, stream);
-        case 8: return launchPairBiasedR<kLo + 8>(a, computeUnits, stream);
-        case 10: return launchPairBiasedR<kLo + 10>(a, computeUnits, stream);
-        case 12: return launchPairBiasedR<kLo + 12>(a, computeUnits, stream);
-        case 14: return launchPairBiasedR<kLo + 14>(a, computeUnits, stream);
+        case 0: return launchPairBiasedR<kLo, LOC>(a, computeUnits, stream);
+        case 2: return launchPairBiasedR<kLo + 2, LOC>(a, computeUnits, stream);
+        case 4: return launchPairBiasedR<kLo + 4, LOC>(a, computeUnits, stream);
+        case 6: return launchPairBiasedR<kLo + 6, LOC>(a, computeUnits, stream);
+        case 8: return launchPairBiasedR<kLo + 8, LOC>(a, computeUnits, stream);
+        case 10: return launchPairBiasedR<kLo + 10, LOC>(a, computeUnits, stream);
+        case 12: return launchPairBiasedR<kLo + 12, LOC>(a, computeUnits, stream);
+        case 14: return launchPairBiasedR<kLo + 14, LOC>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

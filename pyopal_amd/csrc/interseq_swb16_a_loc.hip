@@ -1,0 +1,12 @@
+// One arithmetic flavour of the inter-sequence kernel (see interseq_impl.h): Smith-Waterman on
+// biased integer halves, column-shifted, pair-indexed LDS profile; strips of 2..16 rows, with end
+// locations (row keys in the low bits of every value).
+#include "interseq_impl.h"
+
+namespace miopal {
+
+hipError_t launchInterseqPairSwBiasedLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream) {
+    return launchPairBiased<2, true>(a, rows, computeUnits, stream);
+}
+
+}  // namespace miopal
