@@ -41,6 +41,7 @@ struct InterseqArgs {
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
     int priorityChunks;        // groups with more chunks than this raise their wave priority
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
+    int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
@@ -168,13 +169,13 @@ enum PairFlavour : int {
 constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
 constexpr int kBiasedMaxMagnitude = 1024;  // |score|, open - ext, ext - open
 constexpr int kBiasedMaxExt = 512;
+constexpr int kBiasedMaxStepUp = 0x1000;   // (score + ext) << bits, (ext - open) << bits; above 0x0400 the limit shrinks
 constexpr int kBiasedPad = -1024;          // = kBiasedPadScore: padding symbol / rows in the profile
 // the biased flavour with end locations (scaled by 2^bits, bits = 4 / 5 / 6 for <= 16 / 32 / 64 rows)
 constexpr int kLocZeroPattern = 0x0C00;
 constexpr int kLocGuardBand = 0x0800;      // |score| << bits, (open - ext) << bits, (ext - open) << bits
 constexpr int kLocMaxShift = 4096;         // 5 * (ext << bits) must fit
 inline int locRowBitsHost(int rows) { return rows <= 16 ? 4 : rows <= 32 ? 5 : 6; }
-inline int locLimitHost(int rows) { return (0x7C00 - kLocZeroPattern - kLocMaxShift) >> locRowBitsHost(rows); }
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream, bool locate = false);
 hipError_t launchInterseqPairSwBiasedA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

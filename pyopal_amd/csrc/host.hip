@@ -896,11 +896,18 @@ struct Search {
             const int bits = locate ? locRowBitsHost(pairRows) : 0;
             const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
             const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
+            // (A step up of more than 0x0400 could carry a finite half past the NaN patterns, 0x7C00 to
+            // 0x7FFF, into the negative ones, where the max would drop it: the limit is then lowered
+            // by the excess, so that the cell it would jump from is itself flagged.)
             const bool biasedFits = nStrips == 1 && useHalf && !getenv("MIOPAL_NO_BIASED") &&
-                                    (up << bits) <= 0x0400 && (down << bits) <= (locate ? kLocGuardBand : kBiasedMaxMagnitude) &&
+                                    (up << bits) <= kBiasedMaxStepUp &&
+                                    (down << bits) <= (locate ? kLocGuardBand : kBiasedMaxMagnitude) &&
                                     5 * ((int64_t)ext << bits) <= kLocMaxShift && minScore > kBiasedPad;
+            const int biasedLimit =
+                (int)(((locate ? 0x7C00 - kLocZeroPattern - kLocMaxShift : kBiasedScoreLimit) -
+                       std::max<int64_t>(0, (up << bits) - 0x0400)) >> bits);
             const bool usePair = sw && nStrips == 1 && !(noPair && noPair[0] == '1') &&
-                                 interseqPairFits(locate ? pairRows : rows, nSym) && (!locate || biasedFits);
+                                 interseqPairFits(biasedFits ? pairRows : rows, nSym) && (!locate || biasedFits);
             const bool biased = usePair && biasedFits;
             // Half floats turn a sum above 65504 into +inf, and inf + (-inf padding) into NaN, which
             // the flag `best >= 2048` would miss (NaN converts to 0): only matrices whose best
@@ -970,7 +977,7 @@ struct Search {
             RC_TRY(ws->stageUpload(pp, prof.data(), prof.size() * sizeof(prof[0]), stream));
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
             const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
-            const int64_t limit = biased ? (locate ? locLimitHost(pairRows) : kBiasedScoreLimit) : halfFloat ? 2048 : 32767;
+            const int64_t limit = biased ? biasedLimit : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
@@ -999,6 +1006,7 @@ struct Search {
                 ia.endJ = (int32_t*)vj;
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
+            ia.biasedLimit = biasedLimit;
             ia.boundaryOff = view->d_boundaryOff;
             ia.priorityChunks = getenv("MIOPAL_NO_PRIORITY") ? INT32_MAX : (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
             if ((nStrips + waves - 1) / waves > 1) {

@@ -1065,9 +1065,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
             a.endJ[base + kLanes + lane] = colB;
         }
         if (a.overflow) {
-            constexpr int kLimit = LOC ? locLimit(kBits) : kBiasedLimit;
-            a.overflow[base + lane] = lo >= kLimit;
-            a.overflow[base + kLanes + lane] = hi >= kLimit;
+            // (at most locLimit(kBits) / kBiasedLimit; lower when single steps are large, host.hip)
+            a.overflow[base + lane] = lo >= a.biasedLimit;
+            a.overflow[base + kLanes + lane] = hi >= a.biasedLimit;
         }
     }
 }

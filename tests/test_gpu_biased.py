@@ -1,0 +1,195 @@
+"""The biased-integer lanes of the pair-table kernel (interseq_impl.h: scores, and scores with
+end locations) against the CPU checker: every strip height, the edges of the exact range (lanes
+that must be flagged and redone), rebasing of the column shift, gap models on both sides of
+open == ext, ragged groups. Bit-exact, through the C ABI."""
+import numpy as np
+import pytest
+
+import _data
+import _oracle
+from pyopal_amd.matrices import ScoringMatrix
+
+pytestmark = pytest.mark.gpu
+
+B62 = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+PAIR_BIASED = 4  # miopalLastRouting counts[1]: 2 + kPairSwBiased
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from pyopal_amd import _capi
+    assert _capi.lib().miopalDeviceCount() >= 1, "no gfx950 device visible"
+    return _capi
+
+
+def check(capi, query, res, off, matrix, go, ge, modes=("score", "end"), expect_kernel=PAIR_BIASED, tag=""):
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for mode in modes:
+            got = db.search(query, matrix, go, ge, mode, "sw")
+            kernel = capi.DeviceDatabase.last_routing()[1]
+            want = _oracle.search(query, res, off, matrix, go, ge, mode, "sw")
+            for key in want:
+                if key == "aln":
+                    for k, (a, b) in enumerate(zip(got[key], want[key])):
+                        assert a.tolist() == b.tolist(), f"{tag} {mode} alignment {k}"
+                else:
+                    np.testing.assert_array_equal(got[key], want[key], err_msg=f"{tag} {mode} {key}")
+            if expect_kernel is not None:
+                assert kernel == expect_kernel, f"{tag} {mode}: lane-per-target pass ran kernel {kernel}"
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("qlen", list(range(1, 65)))
+def test_every_strip_height(capi, qlen):
+    rng = np.random.default_rng(1000 + qlen)
+    query = _data.random_protein(rng, qlen)
+    lengths = rng.integers(1, 120, size=300)
+    res, off = _data.random_db(rng, lengths)
+    # a few related targets: scores well above the random background, ends away from the borders
+    pieces, lens = [], []
+    for k in range(20):
+        t = np.concatenate([_data.random_protein(rng, int(rng.integers(0, 30))), _data.mutate(rng, query, 0.1),
+                            _data.random_protein(rng, int(rng.integers(0, 30)))])
+        pieces.append(t)
+        lens.append(len(t))
+    res = np.concatenate([res] + pieces)
+    off = np.concatenate([off, off[-1] + np.cumsum(lens)])
+    # the pair table of the 25-symbol alphabet fits the CU's LDS up to 60 rows (15 slots of 16 bytes
+    # per row); taller strips take the general kernel
+    rows = max(2, (qlen + 1) // 2 * 2)
+    fits = 25 * 25 * (((rows + 3) // 4) | 1) * 16 <= 158 * 1024
+    check(capi, query, res, off, B62, 3, 1, expect_kernel=PAIR_BIASED if fits else 1, tag=f"Q={qlen}")
+
+
+@pytest.mark.parametrize("go,ge", [(3, 1), (11, 1), (1, 1), (2, 5), (0, 3), (5, 0), (14, 12), (40, 12)])
+def test_gap_models(capi, go, ge):
+    rng = np.random.default_rng(go * 100 + ge)
+    query = _data.random_protein(rng, 53)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=400)]
+    seqs += [_data.mutate(rng, query, 0.2) for _ in range(40)]
+    res, off = _oracle.flatten(seqs)
+    # (a gap model outside the guard band of the flavour must fall back, not fail: no kernel check)
+    check(capi, query, res, off, B62, go, ge, expect_kernel=None, tag=f"gap {go}/{ge}")
+
+
+def test_column_shift_is_rebased(capi):
+    # ext = 12 with end locations (6 row bits): 768 pattern units per column, a rebase every
+    # chunk (and steps up of 23 << 6: the lowered limit); scores-only at ext = 400: a rebase every
+    # other chunk. Targets long enough for dozens.
+    rng = np.random.default_rng(77)
+    query = _data.random_protein(rng, 60)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(200, 1500, size=260)]
+    seqs += [np.concatenate([_data.random_protein(rng, 700), _data.mutate(rng, query, 0.05)]) for _ in range(10)]
+    res, off = _oracle.flatten(seqs)
+    check(capi, query, res, off, B62, 14, 12, tag="ext 12")
+    check(capi, query, res, off, B62, 500, 400, modes=("score",), tag="ext 400")
+
+
+def test_long_targets_many_rebases_at_unit_extension(capi):
+    rng = np.random.default_rng(78)
+    query = _data.encode(_data.README_QUERY)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(4000, 8000, size=130)]
+    seqs[5] = np.concatenate([seqs[5][:6000], _data.mutate(rng, query, 0.05), seqs[5][6000:6100]])
+    res, off = _oracle.flatten(seqs)
+    # (Smith-Waterman searches of long targets use segmented views: windows, still the same kernel)
+    check(capi, query, res, off, B62, 3, 1, tag="long targets")
+
+
+def scaled_identity(A, match, mismatch):
+    m = np.full((A, A), mismatch, dtype=np.int32)
+    np.fill_diagonal(m, match)
+    return m.ravel()
+
+
+@pytest.mark.parametrize("match,qlen", [(15, 60), (15, 30), (15, 16), (11, 53)])
+def test_end_location_range_is_left_and_lanes_are_redone(capi, match, qlen):
+    # exact copies of the query score match * qlen: 900 at 60 rows (limit 384 at 6 row bits),
+    # 450 at 30 rows (limit 768), 240 at 16 rows (limit 1536), 583 at 53 rows
+    rng = np.random.default_rng(match * 100 + qlen)
+    m = scaled_identity(24, match, -4)
+    query = _data.random_protein(rng, qlen)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 200, size=300)]
+    for frac in (1.0, 0.9, 0.7, 0.5, 0.41, 0.4, 0.39, 0.3):   # scores on both sides of the limits
+        k = max(1, int(qlen * frac))
+        seqs.append(np.concatenate([_data.random_protein(rng, 17), query[:k], _data.random_protein(rng, 9)]))
+        seqs.append(np.concatenate([query[qlen - k:], _data.random_protein(rng, 23)]))
+    res, off = _oracle.flatten(seqs)
+    check(capi, query, res, off, m, 5, 2, tag=f"match {match} Q={qlen}")
+
+
+def test_score_range_is_left_and_lanes_are_redone(capi):
+    # match 500: copies of k query residues score 500 k, the flavour is exact below 25600 (k = 51)
+    rng = np.random.default_rng(5)
+    m = scaled_identity(24, 500, -300)
+    query = _data.random_protein(rng, 60)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 200, size=300)]
+    for k in (60, 56, 53, 52, 51, 50, 49, 40, 10):
+        seqs.append(np.concatenate([_data.random_protein(rng, 11), query[:k], _data.random_protein(rng, 5)]))
+    res, off = _oracle.flatten(seqs)
+    check(capi, query, res, off, m, 700, 100, modes=("score",), tag="match 500")
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        db.search(query, m, 700, 100, "score", "sw")
+        assert capi.DeviceDatabase.last_routing()[3] >= 4   # the copies of 52+ residues were redone
+    finally:
+        db.close()
+
+
+def test_many_lanes_leave_the_range(capi):
+    # more flagged lanes than the direct recompute takes: the whole view runs the next rung
+    rng = np.random.default_rng(6)
+    m = scaled_identity(24, 15, -4)
+    query = _data.random_protein(rng, 60)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 100, size=200)]
+    seqs += [np.concatenate([_data.random_protein(rng, int(rng.integers(0, 9))), query]) for _ in range(2300)]
+    res, off = _oracle.flatten(seqs)
+    check(capi, query, res, off, m, 5, 2, modes=("end",), expect_kernel=None, tag="many flagged")
+
+
+def test_large_steps_lower_the_limit(capi):
+    # match + ext = 3000 > 0x0400: a finite half could jump over the NaN patterns; the limit is
+    # lowered by the excess so that the cell it would jump from is flagged
+    rng = np.random.default_rng(18)
+    m = scaled_identity(24, 2900, -900)
+    query = _data.random_protein(rng, 40)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 100, size=200)]
+    seqs += [np.concatenate([query[:k], _data.random_protein(rng, 3)]) for k in (40, 12, 11, 10, 9, 8, 7, 6, 5)]
+    res, off = _oracle.flatten(seqs)
+    check(capi, query, res, off, m, 1000, 100, modes=("score",), tag="match 2900")
+
+
+def test_steps_up_beyond_the_guard_band_take_another_flavour(capi):
+    # match + ext > 0x1000: the flavour must not run
+    rng = np.random.default_rng(8)
+    m = scaled_identity(24, 4100, -900)
+    query = _data.random_protein(rng, 40)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 100, size=200)]
+    seqs += [np.concatenate([query[:k], _data.random_protein(rng, 3)]) for k in (40, 33, 32, 31, 5)]
+    res, off = _oracle.flatten(seqs)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for mode in ("score", "end"):
+            got = db.search(query, m, 1200, 100, mode, "sw")
+            assert capi.DeviceDatabase.last_routing()[1] != PAIR_BIASED
+            want = _oracle.search(query, res, off, m, 1200, 100, mode, "sw")
+            for key in want:
+                np.testing.assert_array_equal(got[key], want[key], err_msg=f"{mode} {key}")
+    finally:
+        db.close()
+
+
+def test_switch_restores_the_half_float_rung(capi, monkeypatch):
+    rng = np.random.default_rng(9)
+    query = _data.encode(_data.README_QUERY)
+    res, off = _data.random_db(rng, rng.integers(20, 300, size=500))
+    monkeypatch.setenv("MIOPAL_NO_BIASED", "1")
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(query, B62, 3, 1, "score", "sw")
+        assert capi.DeviceDatabase.last_routing()[1] == 3   # pair table, half floats
+        want = _oracle.search(query, res, off, B62, 3, 1, "score", "sw")
+        np.testing.assert_array_equal(got["score"], want["score"])
+    finally:
+        db.close()
