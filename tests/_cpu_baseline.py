@@ -23,6 +23,10 @@ def lib():
         _LIB.cpuSimdSearchSW.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_int]
+        _LIB.cpuSimdSearchGlobal.restype = ctypes.c_int
+        _LIB.cpuSimdSearchGlobal.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_int]
         _LIB.cpuSimdThreads.restype = ctypes.c_int
     return _LIB
 
@@ -41,6 +45,19 @@ class CpuDatabase:
         out = np.zeros(self.n, dtype=np.int32)
         rc = lib().cpuSimdSearchSW(self.h, q.ctypes.data, len(q), gap_open, gap_extend, S.ctypes.data,
                                    self.A, out.ctypes.data, threads)
+        if rc != 0:
+            raise RuntimeError(f"cpu baseline failed ({rc})")
+        return out
+
+    def search(self, query, matrix, gap_open=3, gap_extend=1, algorithm="sw", threads=0):
+        """Scores under any of the four algorithms (nw / hw / ov: 16-bit lanes + 64-bit scalar)."""
+        if algorithm == "sw":
+            return self.search_sw(query, matrix, gap_open, gap_extend, threads)
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        S = np.ascontiguousarray(matrix, dtype=np.int32)
+        out = np.zeros(self.n, dtype=np.int32)
+        rc = lib().cpuSimdSearchGlobal(self.h, q.ctypes.data, len(q), gap_open, gap_extend, S.ctypes.data,
+                                       self.A, {"nw": 0, "hw": 1, "ov": 2}[algorithm], out.ctypes.data, threads)
         if rc != 0:
             raise RuntimeError(f"cpu baseline failed ({rc})")
         return out

@@ -39,3 +39,34 @@ def test_overflow_ladder():
         np.testing.assert_array_equal(got, want)
     assert want.max() > 32767
     db.close()
+
+
+@pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
+def test_global_modes_match_the_oracle(algo):
+    rng = np.random.default_rng(11)
+    lengths = np.concatenate([rng.integers(1, 400, size=300), [0, 1, 2, 399, 400]])
+    res, off = _data.random_db(rng, lengths)
+    db = _cpu_baseline.CpuDatabase(res, off)
+    for qlen in (1, 53, 200):
+        q = _data.random_protein(rng, qlen)
+        for m, go, ge in ((B62, 3, 1), (B50, 11, 1), (B62, 2, 5), (B62, 0, 0)):
+            got = db.search(q, m, go, ge, algo, 2)
+            want = _oracle.search(q, res, off, m, go, ge, "score", algo)["score"]
+            np.testing.assert_array_equal(got, want, err_msg=f"{algo} Q={qlen} gap {go}/{ge}")
+    db.close()
+
+
+@pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
+def test_global_modes_leave_16_bits(algo):
+    # the reference's overflow test shape (src/pyopal/tests/test_aligner.py:24-37): long targets
+    rng = np.random.default_rng(12)
+    q = _data.random_protein(rng, 300)
+    lengths = [300, 1000, 9000, 20000, 35000, 299, 31000]
+    res, off = _data.random_db(rng, lengths)
+    db = _cpu_baseline.CpuDatabase(res, off)
+    got = db.search(q, B62, 3, 1, algo, 2)
+    want = _oracle.search(q, res, off, B62, 3, 1, "score", algo)["score"]
+    np.testing.assert_array_equal(got, want)
+    if algo == "nw":
+        assert want.min() < -32768
+    db.close()

@@ -1,6 +1,6 @@
-"""Full-size checks at BASELINE.json's configurations (sizes the scalar checker
-cannot finish): every score against the AVX2 CPU baseline for Smith-Waterman,
-and size-independent properties for the other modes."""
+"""Full-size checks at BASELINE.json's configurations, at BASELINE size: every score against the
+AVX2 CPU checker (all four modes), every end location and every alignment of the 1M-target
+database against the scalar checker run on the host cores, frozen whole-database checksums."""
 import numpy as np
 import pytest
 
@@ -9,8 +9,11 @@ import _data
 import _oracle
 from pyopal_amd.matrices import ScoringMatrix
 
+import os
+
 pytestmark = pytest.mark.gpu
 B62 = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+THREADS = max(1, min(16, os.cpu_count() or 1))  # host threads of the CPU checkers
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +31,7 @@ def test_cfg2_every_score(capi):
     db = capi.DeviceDatabase(res, off, 24)
     gpu = db.search(q, B62, 3, 1, "score", "sw")["score"]
     cpu = _cpu_baseline.CpuDatabase(res, off)
-    want = cpu.search_sw(q, B62, 3, 1, 16)
+    want = cpu.search_sw(q, B62, 3, 1, THREADS)
     cpu.close()
     np.testing.assert_array_equal(gpu, want)
     # idempotence and slice consistency on the resident database
@@ -45,20 +48,51 @@ def test_cfg2_every_score(capi):
     db.close()
 
 
-def test_cfg3_full_alignments_sample_and_invariants(capi):
-    # configs[2]: SW full on the cfg2 database (a 200k slice keeps host memory modest)
+def test_cfg2_every_end_location(capi):
+    # configs[1] with end locations: all 1M (score, end_q, end_t) against the scalar checker
     rng = np.random.default_rng(1)
-    n = 200_000
+    res, off = _data.random_db(rng, np.full(1_000_000, 300))
+    q = _oracle.encode(_data.README_QUERY)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        end = db.search(q, B62, 3, 1, "end", "sw")
+    finally:
+        db.close()
+    ref = _oracle.search_parallel(q, res, off, B62, 3, 1, "end", "sw", THREADS)
+    for key in ("score", "end_q", "end_t"):
+        np.testing.assert_array_equal(end[key], ref[key], err_msg=key)
+
+
+# sums over the whole cfg3 result, from the scalar checker (tests/golden/make_cfg3_checksum.py)
+CFG3_SCORE_SUM = 57_737_236
+CFG3_ALIGNMENT_BYTES = 66_834_735
+CFG3_OPS_CRC32 = 0x6BCA4F59
+
+
+def test_cfg3_every_alignment(capi):
+    # configs[2]: SW full on the whole cfg2 database, 1M x 300. Every score, end, start and
+    # alignment operation against the scalar checker (run here on the host cores), and the
+    # frozen whole-database checksums.
+    import zlib
+    rng = np.random.default_rng(1)
+    n = 1_000_000
     res, off = _data.random_db(rng, np.full(n, 300))
     q = _oracle.encode(_data.README_QUERY)
     db = capi.DeviceDatabase(res, off, 24)
-    out = db.search(q, B62, 3, 1, "full", "sw")
-    ref = _oracle.search(q, res[:off[3000]], off[:3001], B62, 3, 1, "full", "sw")
-    for key in ("score", "end_q", "end_t", "start_q", "start_t"):
-        np.testing.assert_array_equal(out[key][:3000], ref[key])
-    assert all(a.tolist() == b.tolist() for a, b in zip(out["aln"][:3000], ref["aln"]))
-    # every alignment re-scores to its reported score and spans [start, end]
+    try:
+        out = db.search(q, B62, 3, 1, "full", "sw")
+    finally:
+        db.close()
     flat, aoff = out["aln_flat"], out["aln_off"]
+    assert int(out["score"].sum()) == CFG3_SCORE_SUM
+    assert int(aoff[-1]) == CFG3_ALIGNMENT_BYTES == len(flat)
+    assert zlib.crc32(np.ascontiguousarray(flat).tobytes()) == CFG3_OPS_CRC32
+    ref = _oracle.search_parallel(q, res, off, B62, 3, 1, "full", "sw", THREADS)
+    for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+        np.testing.assert_array_equal(out[key], ref[key], err_msg=key)
+    np.testing.assert_array_equal(aoff, ref["aln_off"])
+    np.testing.assert_array_equal(flat, ref["aln_flat"])
+    # every sampled alignment re-scores to its reported score and spans [start, end]
     S = B62.reshape(24, 24)
     for k in rng.integers(0, n, size=2000):
         ops = flat[aoff[k]:aoff[k + 1]]
@@ -75,29 +109,46 @@ def test_cfg3_full_alignments_sample_and_invariants(capi):
                 else: j += 1
         assert score == out["score"][k]
         assert i - 1 == out["end_q"][k] and j - 1 - off[k] == out["end_t"][k]
-    db.close()
 
 
-def test_cfg4_mode_ordering_and_sample(capi):
-    # configs[3]: 2000-aa query vs 2000-aa targets (20k of the 100k keep the run short),
-    # plus the long tail that forces 32-bit lanes. NW <= HW <= OV <= SW holds for any
-    # pair because each mode frees more of the borders than the one before.
+def test_cfg4_every_score_all_modes(capi):
+    # configs[3]: 2000-aa query vs 100k x 2000 plus the 35 long targets of the reference's overflow
+    # test (1000 ... 35000 residues, src/pyopal/tests/test_aligner.py:31-34), which really leave
+    # 16 bits. NW, HW, OV and SW: every score against the AVX2 CPU checker (itself held to the
+    # scalar checker by tests/test_cpu_baseline.py), 500 targets per mode (the whole tail among
+    # them) against the scalar checker, end locations of 100, and NW <= HW <= OV <= SW.
     rng = np.random.default_rng(2)
-    lengths = np.concatenate([np.full(20_000, 2000), np.arange(1000, 52000, 10000)])
+    n_main = 100_000
+    lengths = np.concatenate([np.full(n_main, 2000), np.arange(1000, 35001, 1000)])
+    n = len(lengths)
     res, off = _data.random_db(rng, lengths)
     q = _data.random_protein(rng, 2000)
+    tail = np.arange(n_main, n)
+    sample = np.concatenate([rng.choice(n_main, size=500 - len(tail), replace=False), tail])
+    sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+    ends = np.concatenate([sample[:90], tail[:10]])
+    eres, eoff = _oracle.flatten([res[off[k]:off[k + 1]] for k in ends])
+    cpu = _cpu_baseline.CpuDatabase(res, off)
     db = capi.DeviceDatabase(res, off, 24)
-    scores = {a: db.search(q, B62, 3, 1, "score", a)["score"] for a in ("nw", "hw", "ov", "sw")}
+    scores = {}
+    try:
+        for algo in ("nw", "hw", "ov", "sw"):
+            scores[algo] = db.search(q, B62, 3, 1, "score", algo)["score"]
+            want = cpu.search(q, B62, 3, 1, algo, THREADS)
+            np.testing.assert_array_equal(scores[algo], want, err_msg=f"{algo}: every score")
+            ref = _oracle.search_parallel(q, sres, soff, B62, 3, 1, "score", algo, THREADS, chunk=4)["score"]
+            np.testing.assert_array_equal(scores[algo][sample], ref, err_msg=f"{algo}: scalar checker")
+            end = db.search(q, B62, 3, 1, "end", algo)
+            np.testing.assert_array_equal(end["score"], scores[algo], err_msg=f"{algo}: end vs score mode")
+            ref = _oracle.search_parallel(q, eres, eoff, B62, 3, 1, "end", algo, THREADS, chunk=4)
+            for key in ("score", "end_q", "end_t"):
+                np.testing.assert_array_equal(end[key][ends], ref[key], err_msg=f"{algo} {key}")
+    finally:
+        db.close()
+        cpu.close()
     assert (scores["nw"] <= scores["hw"]).all() and (scores["hw"] <= scores["ov"]).all()
     assert (scores["ov"] <= scores["sw"]).all() and (scores["sw"] >= 0).all()
-    assert scores["nw"].min() < -32768 < 32767  # the tail really leaves 16 bits
-    sample = [0, 1, 19_999, 20_000, 20_003, 20_005]
-    sub = [res[off[k]:off[k + 1]] for k in sample]
-    sres, soff = _oracle.flatten(sub)
-    for algo in ("nw", "hw", "ov", "sw"):
-        ref = _oracle.search(q, sres, soff, B62, 3, 1, "score", algo)["score"]
-        np.testing.assert_array_equal(scores[algo][sample], ref)
-    db.close()
+    assert scores["nw"].min() < -32768  # the tail really leaves 16 bits
 
 
 def test_cfg5_whole_database_on_one_gpu(capi):
@@ -117,7 +168,7 @@ def test_cfg5_whole_database_on_one_gpu(capi):
         for lo in (0, 5_368_000, n - 200_000):      # 5_368_709 * 400 = 2^31
             hi = lo + 200_000
             cpu = _cpu_baseline.CpuDatabase(res[off[lo]:off[hi]], off[lo:hi + 1] - off[lo])
-            want = cpu.search_sw(q, B62, 3, 1, 16)
+            want = cpu.search_sw(q, B62, 3, 1, THREADS)
             cpu.close()
             np.testing.assert_array_equal(gpu[lo:hi], want, err_msg=f"targets {lo}..{hi}")
         for lo in (0, 5_368_700, n - 500):
