@@ -134,6 +134,10 @@ def test_cfg4_every_score_all_modes(capi):
     try:
         for algo in ("nw", "hw", "ov", "sw"):
             scores[algo] = db.search(q, B62, 3, 1, "score", algo)["score"]
+            if algo != "sw":
+                # the tail really leaves 16 bits: cells of a 2000 x L matrix reach -(2000 + L) and
+                # below, the targets of 30000 residues and more were computed by the int32 kernel
+                assert capi.DeviceDatabase.last_routing()[0] >= 6, capi.DeviceDatabase.last_routing()
             want = cpu.search(q, B62, 3, 1, algo, THREADS)
             np.testing.assert_array_equal(scores[algo], want, err_msg=f"{algo}: every score")
             ref = _oracle.search_parallel(q, sres, soff, B62, 3, 1, "score", algo, THREADS, chunk=4)["score"]
@@ -148,7 +152,6 @@ def test_cfg4_every_score_all_modes(capi):
         cpu.close()
     assert (scores["nw"] <= scores["hw"]).all() and (scores["hw"] <= scores["ov"]).all()
     assert (scores["ov"] <= scores["sw"]).all() and (scores["sw"] >= 0).all()
-    assert scores["nw"].min() < -32768  # the tail really leaves 16 bits
 
 
 def test_cfg5_whole_database_on_one_gpu(capi):
