@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_line_small_workload():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
-                          "--warmup", "1", "--targets", "50000"], capture_output=True, text=True, timeout=600)
+                          "--warmup", "1", "--targets", "50000", "--cfg5-targets", "250000", "--cfg5-steps", "2"],
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -29,6 +30,15 @@ def test_bench_line_small_workload():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "GCUPS"
     assert line["value"] > cpu["value"]
+    # what the line says about itself: the host-visible form beside `value`, an honest CPU leg,
+    # PMC-derived numbers only for the build they were measured on
+    assert line["value_host_results"] and line["value_host_results"] <= line["value"] * 1.05
+    assert "scores left in HBM" in line["config"]["workload"]
+    assert cpu["value_one_thread"] > 0 and cpu["cpu_model"] and cpu["host_physical_cores"] >= cpu["cores"] >= 1
+    assert roof["traffic"] is None    # 50k targets is not the profiled workload
+    assert set(roof["valu_issue"]) >= {"achieved", "full_rate_peak", "frac", "cycles_per_instruction"}
+    strong = line["extras"]["cfg5_strong"]
+    assert strong["scaling"] == "strong" and strong["gcups"] > 0 and sum(strong["targets_per_rank"]) == 250000
 
 
 def test_bench_refuses_to_run_without_gpu():

@@ -21,7 +21,12 @@ for d in sys.argv[4:]:
                 agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, v in agg.items():
             counters[k] = {"launches": len(v), "mean_per_launch": sum(v) / len(v)}
+import hashlib
+lib_path = os.environ.get("MIOPAL_LIBRARY") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                            "pyopal_amd", "libmiopal.so")
 summary = {
+    # bench.py only quotes these counters for the build they were measured on
+    "library_sha256": hashlib.sha256(open(lib_path, "rb").read()).hexdigest(),
     "command": os.environ.get(
         "PMC_COMMAND",
         "rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 bench.py --steps 5 "
