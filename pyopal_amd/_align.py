@@ -2,9 +2,12 @@
 
 Same generator contract (``threads``, ``pool``, ``ordered``, contiguous chunks of
 ``len(database) // threads`` targets). The chunks are searched concurrently
-through the C ABI (GIL released) and dealt round-robin over the visible GPUs,
-each GPU holding its own mirror of the database: chunks are independent, so no
-collective is involved.
+through the C ABI (GIL released). With several GPUs visible the database is cut
+into one contiguous shard per GPU with (nearly) equal residue counts
+(`shard.balanced_bounds`: equal DP cells per GPU), every GPU
+uploads and keeps only its shard, and a chunk is searched on the GPU(s) whose shard
+it lies in - split at the shard boundary when it straddles one. Chunks are
+independent, so no collective is involved; target indices are absolute.
 """
 
 from __future__ import annotations
@@ -13,8 +16,11 @@ import contextlib
 import multiprocessing.pool
 import typing
 
+import numpy as np
+
 from . import _capi
 from .lib import Aligner, BaseDatabase, Database, ScoreResult, resolve_scoring_matrix
+from .shard import balanced_bounds
 
 
 def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend: int = 1,
@@ -35,22 +41,42 @@ def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend
 
     devices = max(1, _capi.lib().miopalDeviceCount())
     chunks = min(threads or devices, size or 1)
-    if chunks == 1:
+    if chunks == 1 and devices == 1:
         # one search on the calling thread
         yield from aligner.align(query, targets, **options)
         return
 
-    # contiguous chunks of size // chunks targets (the remainder makes one more, short chunk,
-    # as in the reference), chunk k on GPU k mod devices
-    step = size // chunks
-    jobs = [(begin, begin + step, k % devices) for k, begin in enumerate(range(0, size, step))]
+    # one contiguous shard per GPU, balanced by residues
+    if devices > 1:
+        with targets.lock.read:
+            lengths = np.fromiter(targets._get_lengths(), dtype=np.int64)[:size]
+        offsets = np.zeros(size + 1, dtype=np.int64)
+        np.cumsum(lengths, out=offsets[1:])
+        bounds = balanced_bounds(offsets, devices)
+    else:
+        bounds = [0, size]
 
-    def search(job):
-        begin, stop, device = job
-        return aligner.align(query, targets, start=begin, end=stop, device=device, **options)
+    # contiguous chunks of size // chunks targets (the remainder makes one more, short chunk,
+    # as in the reference); a chunk is cut where it crosses a shard boundary
+    step = max(1, size // chunks)
+    jobs = []
+    for begin in range(0, size, step):
+        stop = min(begin + step, size)
+        pieces = []
+        for d in range(devices):
+            lo, hi = max(begin, bounds[d]), min(stop, bounds[d + 1])
+            if lo < hi:
+                pieces.append((lo, hi, d, (bounds[d], bounds[d + 1]) if devices > 1 else None))
+        jobs.append(pieces)
+
+    def search(pieces):
+        hits = []
+        for begin, stop, device, part in pieces:
+            hits.extend(aligner.align(query, targets, start=begin, end=stop, device=device, shard=part, **options))
+        return hits
 
     with contextlib.ExitStack() as stack:
-        workers = pool if pool is not None else stack.enter_context(multiprocessing.pool.ThreadPool(chunks))
+        workers = pool if pool is not None else stack.enter_context(multiprocessing.pool.ThreadPool(len(jobs)))
         results = workers.imap(search, jobs) if ordered else workers.imap_unordered(search, jobs)
         for hits in results:
             yield from hits

@@ -236,22 +236,31 @@ class BaseDatabase:
         raise NotImplementedError("BaseDatabase.get_sequences")
 
     # -- device mirror -----------------------------------
-    def _device_mirror(self, device: int = 0) -> _capi.DeviceDatabase:
-        """Packed copy of the database in HBM, rebuilt only after a mutation.
-        Called with the read lock held."""
+    def _device_mirror(self, device: int = 0,
+                       shard: typing.Optional[typing.Tuple[int, int]] = None) -> _capi.DeviceDatabase:
+        """Packed copy of the database - or of its targets ``[lo, hi)`` only, when ``shard`` is
+        given (`pyopal_amd.align` on several GPUs: every GPU holds 1/N of the residues) - in the
+        HBM of ``device``, rebuilt only after a mutation. Called with the read lock held."""
+        key = (device, shard)
         with self._mirror_guard:
-            entry = self._mirrors.get(device)
-            if entry is not None and entry[0] == self._version:
-                return entry[1]
+            # mirrors of an older state of the database are dropped whichever is asked for
+            for old in [k for k, (version, _) in self._mirrors.items() if version != self._version]:
+                self._mirrors.pop(old)[1].close()
+            entry = self._mirrors.get(key)
             if entry is not None:
-                entry[1].close()
+                return entry[1]
             seqs = self._get_encoded()
-            lengths = np.fromiter(self._get_lengths(), dtype=np.int64, count=len(seqs))
+            lo, hi = (0, len(seqs)) if shard is None else shard
+            if not 0 <= lo <= hi <= len(seqs):
+                raise IndexError(f"shard [{lo}, {hi}) outside the database")
+            if shard is not None:
+                seqs = seqs[lo:hi]
+            lengths = np.fromiter(self._get_lengths(), dtype=np.int64)[lo:hi]
             offsets = np.zeros(len(seqs) + 1, dtype=np.int64)
             np.cumsum(lengths, out=offsets[1:])
             residues = np.frombuffer(b"".join(seqs), dtype=np.uint8)
             mirror = _capi.DeviceDatabase(residues, offsets, self.alphabet.length, device)
-            self._mirrors[device] = (self._version, mirror)
+            self._mirrors[key] = (self._version, mirror)
             return mirror
 
     def _invalidate(self) -> None:
@@ -535,11 +544,15 @@ class Aligner:
 
     def align(self, query, database: BaseDatabase, *, mode: str = "score",
               overflow: str = "buckets", algorithm: str = "sw", start: int = 0,
-              end: int = UINT32_MAX, device: int = 0) -> typing.List[ScoreResult]:
+              end: int = UINT32_MAX, device: int = 0,
+              shard: typing.Optional[typing.Tuple[int, int]] = None) -> typing.List[ScoreResult]:
         """Align the query to every target of ``database[start:end]``.
 
         Same keywords as the reference (``src/pyopal/lib.pyx:1258-1268``);
-        ``device`` (extension) selects the GPU holding the database mirror.
+        ``device`` (extension) selects the GPU holding the database mirror, ``shard`` (extension)
+        a mirror of the targets ``[lo, hi)`` only, which must contain ``[start, end)``: what
+        `pyopal_amd.align` uses to give every GPU its own part of the database. Target indices
+        of the results are absolute either way.
         ``overflow`` is validated and otherwise ignored: the GPU path picks the
         narrowest exact lane width per target, results are identical.
         """
@@ -578,8 +591,10 @@ class Aligner:
                 # the reference does not guard this case (unsigned underflow at
                 # src/pyopal/platform/pyx.in:62); an IndexError is raised instead
                 raise IndexError("database slice start is past the end of the database")
+            if shard is not None and not (shard[0] <= start and end <= shard[1]):
+                raise IndexError(f"slice [{start}, {end}) outside the shard [{shard[0]}, {shard[1]})")
             return self._search(encoded, database, _mode, _overflow, _algo, self.gap_open,
-                                self.gap_extend, self._int_matrix, start, end, device=device)
+                                self.gap_extend, self._int_matrix, start, end, device=device, shard=shard)
 
 
     def scores(self, query, database: BaseDatabase, *, algorithm: str = "sw", start: int = 0,

@@ -17,7 +17,7 @@ from ..lib import (UINT32_MAX, BaseDatabase, EndResult, FullResult, ScoreResult,
 
 def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, algorithm: int,
               gap_open: int, gap_extend: int, int_matrix, start: int = 0, end: int = UINT32_MAX,
-              device: int = 0) -> typing.List[ScoreResult]:
+              device: int = 0, shard: typing.Optional[typing.Tuple[int, int]] = None) -> typing.List[ScoreResult]:
     if encoded is None or database is None:
         raise TypeError("encoded and database must not be None")
     if mode == _capi.SEARCH["score"]:
@@ -44,7 +44,9 @@ def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, 
         raise RuntimeError("no supported SIMD backend available")
     matrix = _int_matrix_array(int_matrix)
     matrix_size = int(np.sqrt(matrix.shape[0]))
-    mirror = database._device_mirror(device)
+    # (shard: a mirror that holds the targets [lo, hi) only; indices of the results stay absolute)
+    mirror = database._device_mirror(device, shard)
+    base = 0 if shard is None else shard[0]
     query = np.frombuffer(encoded, dtype=np.uint8)
 
     mode_name = ("score", "end", "full")[mode]
@@ -53,7 +55,7 @@ def searchHIP(encoded: bytes, database: BaseDatabase, mode: int, overflow: int, 
         _capi.raise_for(_capi.OPAL_ERR_INVALID_MODE)
     if matrix_size != mirror.alphabet_length:
         raise ValueError("database and score matrix have different alphabets")
-    out = mirror.search(query, matrix, gap_open, gap_extend, mode_name, algo_name, start, end)
+    out = mirror.search(query, matrix, gap_open, gap_extend, mode_name, algo_name, start - base, end - base)
 
     scores = np.ascontiguousarray(out["score"], dtype=np.int32)
     if result_type is ScoreResult:

@@ -84,3 +84,90 @@ def test_balanced_bounds_unit():
     assert b[0] == 0 and b[-1] == 5 and len(b) == 3
     b8 = shard.balanced_bounds(off, 8)   # more ranks than targets: empty shards allowed at the end
     assert b8[0] == 0 and b8[-1] == 5 and len(b8) == 9 and all(y >= x for x, y in zip(b8, b8[1:]))
+
+
+class _FakeDevices:
+    """Two 'GPUs' whose searches are the CPU checker: records what each device was given."""
+
+    def __init__(self, monkeypatch, count=2):
+        import numpy as np
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle
+        from pyopal_amd import _capi
+        self.uploads = []   # (device, targets, residues)
+        self.searches = []  # (device, start, end) in shard coordinates
+        outer = self
+
+        class FakeLib:
+            def miopalDeviceCount(self):
+                return count
+
+        class FakeDatabase:
+            def __init__(self, residues, offsets, alphabet_length, device=0):
+                self.residues = np.array(residues, dtype=np.uint8)
+                self.offsets = np.array(offsets, dtype=np.int64)
+                self.alphabet_length, self.device, self.count = alphabet_length, device, len(offsets) - 1
+                outer.uploads.append((device, self.count, int(self.offsets[-1])))
+
+            def search(self, query, matrix, gap_open, gap_extend, mode, algorithm, start=0, end=None):
+                end = self.count if end is None else min(end, self.count)
+                outer.searches.append((self.device, start, end))
+                off = self.offsets[start:end + 1] - self.offsets[start]
+                res = self.residues[self.offsets[start]:self.offsets[end]]
+                out = _oracle.search(query, res, off, matrix, gap_open, gap_extend, mode, algorithm)
+                if mode == "full":
+                    lens = np.array([len(a) for a in out["aln"]], dtype=np.int64)
+                    out["aln_off"] = np.concatenate([[0], np.cumsum(lens)])
+                    out["aln_flat"] = np.concatenate(out["aln"]) if len(lens) else np.zeros(0, np.uint8)
+                return out
+
+            def close(self):
+                pass
+
+        monkeypatch.setattr(_capi, "lib", lambda: FakeLib())
+        monkeypatch.setattr(_capi, "DeviceDatabase", FakeDatabase)
+
+
+def test_align_shards_the_database_over_devices(monkeypatch):
+    # pyopal_amd.align with two devices: each uploads only its residue-balanced shard, chunks
+    # are cut at the shard boundary, indices are absolute, ordered=True keeps database order
+    import numpy as np
+    fake = _FakeDevices(monkeypatch, 2)
+    import pyopal_amd
+    from pyopal_amd import shard
+    import _data
+    rng = np.random.default_rng(21)
+    lengths = np.concatenate([rng.integers(200, 400, size=30), rng.integers(5, 40, size=170)])  # skewed
+    seqs = ["".join(_data.NCBI[c] for c in _data.random_protein(rng, int(n))) for n in lengths]
+    query = "".join(_data.NCBI[c] for c in _data.random_protein(rng, 25))
+    db = pyopal_amd.Database(seqs)
+    one = pyopal_amd.Aligner()
+    for threads in (0, 2, 3, 7):
+        fake.uploads.clear(); fake.searches.clear(); db._mirrors.clear()
+        for mode in ("score", "full"):
+            got = list(pyopal_amd.align(query, db, mode=mode, algorithm="sw", threads=threads, ordered=True))
+            assert [r.target_index for r in got] == list(range(len(seqs))), (threads, mode)
+            fake_uploads = list(fake.uploads)
+            want = one.align(query, db, mode=mode, algorithm="sw")   # one (fake) device, whole database
+            del fake.uploads[len(fake_uploads):]
+            assert [r.score for r in got] == [r.score for r in want]
+            if mode == "full":
+                key = lambda r: (r.query_start, r.target_start, r.query_end, r.target_end, r.alignment)  # noqa: E731
+                assert [key(r) for r in got] == [key(r) for r in want]
+        off = np.concatenate([[0], np.cumsum(lengths)])
+        bounds = shard.balanced_bounds(off, 2)
+        assert 0 < bounds[1] < 60, bounds   # balanced by residues, not by count (count would give 100)
+        shard_uploads = sorted(set(u for u in fake.uploads if u[1] != len(seqs)))
+        assert shard_uploads == [(0, bounds[1], int(off[bounds[1]])),
+                                 (1, len(seqs) - bounds[1], int(off[-1] - off[bounds[1]]))], fake.uploads
+        # every search stayed inside its device's shard, in shard coordinates
+        for device, start, end in fake.searches:
+            width = bounds[device + 1] - bounds[device]
+            assert 0 <= start <= end <= max(width, len(seqs)), (device, start, end)
+    # unordered: same multiset of results
+    got = sorted((r.target_index, r.score) for r in pyopal_amd.align(query, db, threads=4))
+    assert got == [(r.target_index, r.score) for r in one.align(query, db)]
+    # a mutation drops every shard mirror
+    db.append("ACDE")
+    assert [r.target_index for r in pyopal_amd.align(query, db, threads=2, ordered=True)] == list(range(len(seqs) + 1))
