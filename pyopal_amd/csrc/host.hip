@@ -8,6 +8,7 @@
 // a device-resident database.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -88,6 +89,7 @@ constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent st
 // wavefront for every pair at this count.
 constexpr int64_t kSmallSearch = 4096;
 constexpr size_t kParkedWorkspaceBytes = 64ull << 30;  // idle per-handle workspaces kept at most
+constexpr size_t kMaxCachedViews = 64;                 // packed views per handle (beside the byte budget)
 
 // malloc-backed byte buffer: grows without zero-filling, and its storage can be handed to the
 // caller of the C ABI (who frees it with free()).
@@ -199,6 +201,15 @@ struct Workspace {
         pending.clear();
         pinnedUsed = 0;
         return 0;
+    }
+    // A search that fails after stageDownload() leaves entries that point at the caller's (or the
+    // failed call's local) memory: they must never be copied out by a later search.
+    void abandonDownloads() {
+        if (pending.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        if (aux) (void)hipStreamSynchronize(aux);
+        pending.clear();
+        pinnedUsed = 0;
     }
     // room for `bytes` more in the staging buffer (drains it, and grows it, when needed)
     int reserveStaging(size_t aligned) {
@@ -346,8 +357,16 @@ struct MiopalDb {
     uint8_t* d_residues = nullptr;
     int64_t* d_offsets = nullptr;
 
+    struct ViewSlot {
+        int64_t start, end;
+        int overlap;
+        bool building;                 // placeholder: the view is being built outside the lock
+        std::shared_ptr<View> view;
+    };
     std::mutex viewMutex;
-    std::list<std::shared_ptr<View>> views;  // most recent first
+    std::condition_variable viewReady;
+    std::list<ViewSlot> views;         // most recent first
+    size_t viewBudgetBytes = (size_t)64 << 30;   // set from the device's memory at creation
 
     std::mutex wsMutex;
     std::vector<std::unique_ptr<Workspace>> ownedFree;              // internal streams, idle
@@ -407,6 +426,8 @@ struct WorkspaceLease {
         return 0;
     }
     ~WorkspaceLease() {
+        // downloads still pending here belong to a search that returned an error
+        if (ws) ws->abandonDownloads();
         if (owned && ws) {
             // Idle workspaces keep their buffers for the next search on whatever thread comes
             // first, but not without bound: many threads that each ran one `full` search would
@@ -544,7 +565,17 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
     v->groupChunksHost.assign(groupChunks.begin(), groupChunks.begin() + v->nGroups);
     v->ids = ids;
     if (v->nGroups > 0) {
-        int64_t* d_chunkPrefix = nullptr;
+        // (freed on every exit; the View's own buffers are freed by its destructor)
+        struct DeviceTemp {
+            int64_t* p = nullptr;
+            ~DeviceTemp() { if (p) (void)hipFree(p); }
+        } chunkPrefixTemp;
+        struct BuildStream {
+            hipStream_t s = nullptr;
+            ~BuildStream() { if (s) (void)hipStreamDestroy(s); }
+        } build;
+        HIP_TRY(hipStreamCreateWithFlags(&build.s, hipStreamNonBlocking));
+        int64_t*& d_chunkPrefix = chunkPrefixTemp.p;
         const size_t packBytes = (size_t)groupOff[v->nGroups] * sizeof(uint2);
         HIP_TRY(hipMalloc(&v->d_ids, ids.size() * sizeof(int32_t)));
         HIP_TRY(hipMalloc(&v->d_pack, packBytes));
@@ -578,29 +609,83 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
         pa.nGroups = v->nGroups;
         pa.padSymbol = db->alphabet;
         pa.pack = v->d_pack;
-        HIP_TRY(launchPack(pa, v->totalChunks, nullptr));
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(hipFree(d_chunkPrefix));
-        v->deviceBytes = packBytes + ids.size() * 4 + groupOff.size() * 16 + groupChunks.size() * 4;
+        // (its own stream, and a wait for that stream only: other threads' searches on this device go on)
+        HIP_TRY(launchPack(pa, v->totalChunks, build.s));
+        HIP_TRY(hipStreamSynchronize(build.s));
+        v->deviceBytes = packBytes + ids.size() * 4 + lens.size() * 4 + segStart.size() * 4 +
+                         groupOff.size() * 16 + groupChunks.size() * 4;
     }
     *out = v;
     return 0;
 }
 
+// Cache of packed views, most recent first. A view is about as large as the slice it packs, so
+// the cache is bounded by bytes (a share of the device's memory) as well as by count; thread-chunked
+// callers (src/pyopal/_align.py:150-170) re-use their slice on every query, queries of different
+// lengths add segmented views of the same slice. A view is built OUTSIDE the lock - other threads
+// keep searching their own views meanwhile - behind a placeholder that threads wanting the same
+// view wait on. Views in use are kept alive by their shared_ptr whatever the cache drops.
+void evictViews(MiopalDb* db, size_t budget, size_t keepCount) {
+    size_t total = 0, n = 0;
+    for (const auto& s : db->views) {
+        total += s.view ? s.view->deviceBytes : 0;
+        ++n;
+    }
+    for (auto it = db->views.end(); it != db->views.begin() && (total > budget || n > keepCount);) {
+        --it;
+        if (it->building || it == db->views.begin()) continue;   // never the newest, never one being built
+        total -= it->view ? it->view->deviceBytes : 0;
+        --n;
+        it = db->views.erase(it);
+    }
+}
+
 int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
-    std::lock_guard<std::mutex> g(db->viewMutex);
-    for (auto it = db->views.begin(); it != db->views.end(); ++it) {
-        if ((*it)->start == start && (*it)->end == end && (*it)->overlap == overlap) {
-            *out = *it;
+    std::unique_lock<std::mutex> lk(db->viewMutex);
+    for (;;) {
+        auto it = db->views.begin();
+        for (; it != db->views.end(); ++it)
+            if (it->start == start && it->end == end && it->overlap == overlap) break;
+        if (it == db->views.end()) break;
+        if (!it->building) {
+            *out = it->view;
             db->views.splice(db->views.begin(), db->views, it);
             return 0;
         }
+        db->viewReady.wait(lk);   // somebody is building this very view
     }
-    RC_TRY(buildView(db, start, end, overlap, out));
-    db->views.push_front(*out);
-    // keep the full-database view plus a few slices (thread-chunked callers,
-    // src/pyopal/_align.py:150-170, re-use their slice on every query)
-    while (db->views.size() > 16) db->views.pop_back();
+    db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, true, nullptr});
+    lk.unlock();
+    std::shared_ptr<View> v;
+    int rc = buildView(db, start, end, overlap, &v);
+    if (rc != 0) {
+        // most likely out of device memory: drop every idle view and try once more
+        v.reset();
+        lk.lock();
+        evictViews(db, 0, 1);
+        lk.unlock();
+        (void)hipGetLastError();
+        rc = buildView(db, start, end, overlap, &v);
+    }
+    lk.lock();
+    auto mine = db->views.begin();
+    for (; mine != db->views.end(); ++mine)
+        if (mine->building && mine->start == start && mine->end == end && mine->overlap == overlap) break;
+    if (rc != 0) {
+        if (mine != db->views.end()) db->views.erase(mine);
+        db->viewReady.notify_all();
+        return rc;
+    }
+    if (mine == db->views.end()) {   // (cannot happen: placeholders are only removed by their builder)
+        db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, false, v});
+    } else {
+        mine->view = v;
+        mine->building = false;
+        db->views.splice(db->views.begin(), db->views, mine);
+    }
+    evictViews(db, db->viewBudgetBytes, kMaxCachedViews);
+    db->viewReady.notify_all();
+    *out = v;
     return 0;
 }
 
@@ -1145,6 +1230,10 @@ int createCommon(MiopalDb** out, const unsigned char* residues, const std::vecto
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             db->computeUnits = prop.multiProcessorCount;
+        // cached packed views may take a third of the device's memory (MIOPAL_VIEW_CACHE_MB overrides)
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) db->viewBudgetBytes = totalB / 3;
+        if (const char* mb = getenv("MIOPAL_VIEW_CACHE_MB")) db->viewBudgetBytes = (size_t)std::max(0, atoi(mb)) << 20;
     }
     db->alphabet = alphabetLength;
     db->count = count;
@@ -1225,7 +1314,7 @@ int64_t miopalDbDeviceBytes(const MiopalDb* db) {
     int64_t t = db->total + 64 + (db->count + 1) * 8;
     {
         std::lock_guard<std::mutex> g(m->viewMutex);
-        for (auto& v : m->views) t += (int64_t)v->deviceBytes;
+        for (auto& v : m->views) t += v.view ? (int64_t)v.view->deviceBytes : 0;
     }
     return t;
 }
