@@ -333,14 +333,10 @@ struct View {
     int* d_groupChunks = nullptr;
     int64_t* d_boundaryOff = nullptr;
     size_t deviceBytes = 0;
+    void* d_meta = nullptr;          // one allocation behind d_ids .. d_boundaryOff (and the pack kernel's prefix)
     ~View() {
-        if (d_ids) (void)hipFree(d_ids);
-        if (d_segStart) (void)hipFree(d_segStart);
-        if (d_lens) (void)hipFree(d_lens);
         if (d_pack) (void)hipFree(d_pack);
-        if (d_groupOff) (void)hipFree(d_groupOff);
-        if (d_groupChunks) (void)hipFree(d_groupChunks);
-        if (d_boundaryOff) (void)hipFree(d_boundaryOff);
+        if (d_meta) (void)hipFree(d_meta);
     }
 };
 
@@ -368,6 +364,20 @@ struct MiopalDb {
     std::list<ViewSlot> views;         // most recent first
     size_t viewBudgetBytes = (size_t)64 << 30;   // set from the device's memory at creation
 
+    // pinned staging buffers + streams for view construction, re-used (hipHostMalloc and
+    // hipStreamCreate are slow and serialise between threads)
+    struct UploadChannel {
+        void* pinned = nullptr;
+        size_t cap = 0;
+        hipStream_t stream = nullptr;
+        ~UploadChannel() {
+            if (pinned) (void)hipHostFree(pinned);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    };
+    std::mutex uploadMutex;
+    std::vector<std::unique_ptr<UploadChannel>> uploadFree;
+
     std::mutex wsMutex;
     std::vector<std::unique_ptr<Workspace>> ownedFree;              // internal streams, idle
     std::map<hipStream_t, std::unique_ptr<Workspace>> external;     // caller streams
@@ -379,6 +389,7 @@ struct MiopalDb {
     ~MiopalDb() {
         (void)hipSetDevice(device);
         views.clear();
+        uploadFree.clear();
         ownedFree.clear();
         external.clear();
         if (d_residues) (void)hipFree(d_residues);
@@ -486,6 +497,40 @@ int uploadOnce(void* deviceDst, const void* src, size_t bytes) {
     return 0;
 }
 
+// A staging channel of the handle for the duration of one view construction.
+struct UploadLease {
+    MiopalDb* db;
+    std::unique_ptr<MiopalDb::UploadChannel> ch;
+    explicit UploadLease(MiopalDb* d) : db(d) {}
+    int acquire(size_t bytes) {
+        {
+            std::lock_guard<std::mutex> g(db->uploadMutex);
+            if (!db->uploadFree.empty()) {
+                ch = std::move(db->uploadFree.back());
+                db->uploadFree.pop_back();
+            }
+        }
+        if (!ch) {
+            ch.reset(new MiopalDb::UploadChannel());
+            HIP_TRY(hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking));
+        }
+        if (ch->cap < bytes) {
+            if (ch->pinned) HIP_TRY(hipHostFree(ch->pinned));
+            ch->pinned = nullptr;
+            ch->cap = 0;
+            const size_t want = bytes + bytes / 4 + (1u << 16);
+            HIP_TRY(hipHostMalloc(&ch->pinned, want, hipHostMallocDefault));
+            ch->cap = want;
+        }
+        return 0;
+    }
+    ~UploadLease() {
+        if (!ch) return;
+        std::lock_guard<std::mutex> g(db->uploadMutex);
+        if (db->uploadFree.size() < 32) db->uploadFree.emplace_back(std::move(ch));
+    }
+};
+
 int dbLen(const MiopalDb* db, int64_t id) { return (int)(db->offsets[id + 1] - db->offsets[id]); }
 
 // ---- view construction -------------------------------------------------------
@@ -565,37 +610,41 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
     v->groupChunksHost.assign(groupChunks.begin(), groupChunks.begin() + v->nGroups);
     v->ids = ids;
     if (v->nGroups > 0) {
-        // (freed on every exit; the View's own buffers are freed by its destructor)
-        struct DeviceTemp {
-            int64_t* p = nullptr;
-            ~DeviceTemp() { if (p) (void)hipFree(p); }
-        } chunkPrefixTemp;
-        struct BuildStream {
-            hipStream_t s = nullptr;
-            ~BuildStream() { if (s) (void)hipStreamDestroy(s); }
-        } build;
-        HIP_TRY(hipStreamCreateWithFlags(&build.s, hipStreamNonBlocking));
-        int64_t*& d_chunkPrefix = chunkPrefixTemp.p;
+        // Two device allocations and one staged upload per view: the small per-target and per-group
+        // arrays share one blob (hipMalloc, hipHostMalloc and stream creation serialise in the
+        // runtime, and thread-chunked callers build their slices' views side by side).
         const size_t packBytes = (size_t)groupOff[v->nGroups] * sizeof(uint2);
-        HIP_TRY(hipMalloc(&v->d_ids, ids.size() * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&v->d_pack, packBytes));
-        HIP_TRY(hipMalloc(&v->d_groupOff, groupOff.size() * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&v->d_groupChunks, groupChunks.size() * sizeof(int)));
-        HIP_TRY(hipMalloc(&v->d_boundaryOff, boundaryOff.size() * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&d_chunkPrefix, chunkPrefix.size() * sizeof(int64_t)));
-        RC_TRY(uploadOnce(v->d_ids, ids.data(), ids.size() * sizeof(int32_t)));
         std::vector<int32_t> lens((size_t)v->nGroups * kGroupTargets, 0);
         for (size_t k = 0; k < ids.size(); ++k) lens[k] = vlen[k];
-        if (overlap > 0) {
-            HIP_TRY(hipMalloc(&v->d_segStart, segStart.size() * sizeof(int32_t)));
-            RC_TRY(uploadOnce(v->d_segStart, segStart.data(), segStart.size() * sizeof(int32_t)));
+        struct Part { const void* src; size_t bytes, at; };
+        Part parts[] = {
+            {ids.data(), ids.size() * sizeof(int32_t), 0},
+            {segStart.data(), overlap > 0 ? segStart.size() * sizeof(int32_t) : 0, 0},
+            {lens.data(), lens.size() * sizeof(int32_t), 0},
+            {groupOff.data(), groupOff.size() * sizeof(int64_t), 0},
+            {groupChunks.data(), groupChunks.size() * sizeof(int), 0},
+            {boundaryOff.data(), boundaryOff.size() * sizeof(int64_t), 0},
+            {chunkPrefix.data(), chunkPrefix.size() * sizeof(int64_t), 0},
+        };
+        size_t metaBytes = 0;
+        for (Part& p : parts) {
+            p.at = metaBytes;
+            metaBytes += (p.bytes + 255) & ~(size_t)255;
         }
-        HIP_TRY(hipMalloc(&v->d_lens, lens.size() * sizeof(int32_t)));
-        RC_TRY(uploadOnce(v->d_lens, lens.data(), lens.size() * sizeof(int32_t)));
-        RC_TRY(uploadOnce(v->d_groupOff, groupOff.data(), groupOff.size() * sizeof(int64_t)));
-        RC_TRY(uploadOnce(v->d_groupChunks, groupChunks.data(), groupChunks.size() * sizeof(int)));
-        RC_TRY(uploadOnce(v->d_boundaryOff, boundaryOff.data(), boundaryOff.size() * sizeof(int64_t)));
-        RC_TRY(uploadOnce(d_chunkPrefix, chunkPrefix.data(), chunkPrefix.size() * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&v->d_meta, std::max<size_t>(metaBytes, 256)));
+        HIP_TRY(hipMalloc(&v->d_pack, packBytes));
+        char* meta = (char*)v->d_meta;
+        v->d_ids = (int32_t*)(meta + parts[0].at);
+        v->d_segStart = overlap > 0 ? (int32_t*)(meta + parts[1].at) : nullptr;
+        v->d_lens = (int32_t*)(meta + parts[2].at);
+        v->d_groupOff = (int64_t*)(meta + parts[3].at);
+        v->d_groupChunks = (int*)(meta + parts[4].at);
+        v->d_boundaryOff = (int64_t*)(meta + parts[5].at);
+        UploadLease up(db);
+        RC_TRY(up.acquire(metaBytes));
+        for (const Part& p : parts)
+            if (p.bytes) memcpy((char*)up.ch->pinned + p.at, p.src, p.bytes);
+        HIP_TRY(hipMemcpyAsync(meta, up.ch->pinned, metaBytes, hipMemcpyHostToDevice, up.ch->stream));
         PackArgs pa{};
         pa.residues = db->d_residues;
         pa.offsets = db->d_offsets;
@@ -605,15 +654,14 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
         pa.nTargets = v->nPacked;
         pa.groupOff = v->d_groupOff;
         pa.groupChunks = v->d_groupChunks;
-        pa.chunkPrefix = d_chunkPrefix;
+        pa.chunkPrefix = (const int64_t*)(meta + parts[6].at);
         pa.nGroups = v->nGroups;
         pa.padSymbol = db->alphabet;
         pa.pack = v->d_pack;
-        // (its own stream, and a wait for that stream only: other threads' searches on this device go on)
-        HIP_TRY(launchPack(pa, v->totalChunks, build.s));
-        HIP_TRY(hipStreamSynchronize(build.s));
-        v->deviceBytes = packBytes + ids.size() * 4 + lens.size() * 4 + segStart.size() * 4 +
-                         groupOff.size() * 16 + groupChunks.size() * 4;
+        // (the channel's own stream, and a wait for that stream only: other threads' searches go on)
+        HIP_TRY(launchPack(pa, v->totalChunks, up.ch->stream));
+        HIP_TRY(hipStreamSynchronize(up.ch->stream));
+        v->deviceBytes = packBytes + metaBytes;
     }
     *out = v;
     return 0;
