@@ -97,7 +97,7 @@ struct WalkArgs {
     int64_t opsSlot;
     int32_t* opsLen;
     // direction layout: 0 = intraseq_kernel (anti-diagonal major, at job.dirOff),
-    // > 0 = perpair_kernel ([strip][j][i][lane] per 64 consecutive jobs, this many bytes apart)
+    // > 0 = perpair_kernel ([strip][j][i / 2][lane], 4 bits per cell, per 64 consecutive jobs, this many bytes apart)
     int64_t dirWaveStride;
     int64_t dirStripColumns;  // columns per strip in the perpair_kernel layout
     // hybrid direction pass: jobs at positions below *headWaves x 64 have intraseq_kernel's layout
@@ -123,8 +123,8 @@ struct PerPairArgs {
     int32_t* score;           // by job.out (trace: score of the last cell of the window)
     int32_t* endI;
     int32_t* endJ;
-    uint8_t* dirs;            // trace: [job / 64][strip][j][i][job % 64]
-    int64_t dirWaveStride;    // bytes per 64 consecutive jobs (>= strips * dirStripColumns * 4096)
+    uint8_t* dirs;            // trace: [job / 64][strip][j][i / 2][job % 64], two rows (4 bits each) per byte
+    int64_t dirWaveStride;    // bytes per 64 consecutive jobs (>= strips * dirStripColumns * 2048)
     int64_t dirStripColumns;  // columns reserved per strip (>= longest target window)
     int2* boundary;           // query windows of more than 64 rows: [job / 64][column][job % 64]
     int64_t boundaryStride;   // columns per 64 consecutive jobs (>= longest target window)

@@ -1622,7 +1622,9 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 }
                 // the direction workspace is the one allocation that can be refused on a GPU shared
                 // with other work: halve the batch until it fits
-                while (!ws->tryGet(kDirs, (size_t)(batch * slotDir), &pd)) {
+                // (the lane-per-pair layout packs two rows per byte: half the bytes per pair)
+                const int64_t slotDirUsed = traceLanePerPair ? slotDir / 2 : slotDir;
+                while (!ws->tryGet(kDirs, (size_t)(batch * slotDirUsed), &pd)) {
                     if (batch <= kLanes) return fail(MIOPAL_ERR_HIP, "out of device memory for the traceback workspace");
                     batch = std::max<int64_t>(kLanes, batch / 2 / kLanes * kLanes);
                 }
@@ -1666,7 +1668,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                         pa.nJobs = nb;
                         pa.dirs = (uint8_t*)pd;
                         pa.score = (int32_t*)pts + b0;  // job.out is relative to the batch
-                        pa.dirWaveStride = slotDir * kLanes;
+                        pa.dirWaveStride = slotDirUsed * kLanes;
                         pa.dirStripColumns = maxWindow + kLanes - 1;
                         if (windowStrips > 1) {
                             void* pb;

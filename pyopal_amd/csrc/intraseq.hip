@@ -274,8 +274,10 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
             break;
         }
         const int l = i & 63;
-        const uint8_t d = laneMajor ? dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * kLanes + l) * kLanes]
-                                    : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
+        // perpair_kernel's layout holds two rows per byte ([strip][column][row pair][lane])
+        const uint8_t d = laneMajor
+            ? (uint8_t)((dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * (kLanes / 2) + (l >> 1)) * kLanes] >> ((l & 1) * 4)) & 0xf)
+            : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
         if (state == 0) {
             const int c = d & 3;
             if (c == 0) {

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
         }
         // first maximum of this strip (column-major inside the strip)
         int sbest = INT32_MIN, srow = -1, scol = -1;
-        uint8_t* dcol = MODE == kPerPairTrace ? dirs + (int64_t)s * a.dirStripColumns * (kLanes * kLanes) : nullptr;
+        uint8_t* dcol = MODE == kPerPairTrace ? dirs + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes) : nullptr;
         // row above the strip at column j - 1 (diagonal of the strip's first row)
         int aboveHmPrev = (s == 0 ? 0 : borderGap(row0 - 1, open, ext)) - open;
 
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
             aboveHmPrev = hmUp;
             const bool colOk = j < L, lastCol = j == L - 1;
             const int bestBefore = sbest;
+            int codeEven = 0;
 #pragma unroll
             for (int i = 0; i < kLanes; ++i) {
                 if ((i & 7) == 0 && i >= rowsHere) break;  // wave-uniform
@@ -137,10 +138,12 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
                 const int h = max(d, max(e, f));
                 if (MODE == kPerPairTrace) {
                     // same code as intraseq_kernel<true>: diag > E (target gap) > F (query gap);
-                    // inside a gap, closing it is preferred to extending it
+                    // inside a gap, closing it is preferred to extending it. Four bits per cell:
+                    // rows i, i + 1 share a byte, [column][row pair][lane] (64-byte wave stores)
                     const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
                     const int code = which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0);
-                    dcol[((int64_t)j * kLanes + i) * kLanes] = (uint8_t)code;
+                    if (i & 1) dcol[((int64_t)j * (kLanes / 2) + (i >> 1)) * kLanes] = (uint8_t)(codeEven | (code << 4));
+                    else codeEven = code;
                 } else {
                     bool cand = true;  // kAllCells: pad rows / columns never beat a valid cell
                     if (MODE == kLastRow) cand = colOk && row0 + i == Q - 1;
