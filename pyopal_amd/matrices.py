@@ -75,6 +75,15 @@ _TABLES: typing.Dict[str, str] = {
 }
 
 
+# names the reference resolves through scoring-matrices (src/pyopal/tests/test_aligner.py:10-18 uses
+# VTML80) whose tables are not carried here: see ScoringMatrix.from_name
+_KNOWN_ELSEWHERE = frozenset(
+    ["BENNER6", "BENNER22", "BENNER74", "DAYHOFF", "GONNET", "NUC.4.4", "MATCH", "BLOSUMN"]
+    + [f"BLOSUM{n}" for n in (30, 35, 40, 45, 55, 60, 65, 70, 75, 80, 85, 90, 100)]
+    + [f"PAM{n}" for n in range(10, 510, 10)]
+    + [f"VTML{n}" for n in (10, 20, 40, 80, 120, 160)])
+
+
 class ScoringMatrix:
     """A square substitution matrix over an alphabet.
 
@@ -98,12 +107,43 @@ class ScoringMatrix:
     # --- constructors -----------------------------------------------------
     @classmethod
     def from_name(cls, name: str = "BLOSUM62") -> "ScoringMatrix":
+        """A matrix by its usual name. Resolution order: the tables carried here (BLOSUM50,
+        BLOSUM62: provenance in the module docstring); the ``scoring-matrices`` package the
+        reference uses (``src/pyopal/lib.pyx:1202-1207``) when it is installed; an NCBI-format
+        file ``<name>``, ``<name>.txt`` or ``<name>.mat`` (any case) in one of the directories of
+        ``PYOPAL_AMD_MATRIX_PATH``. The other tables the reference resolves by name (VTML, PAM,
+        the rest of BLOSUM, ...) are deliberately NOT transcribed here: their values are not in the
+        reference tree, and a table typed from memory cannot be vouched for entry by entry."""
+        text = _TABLES.get(name)
+        if text is not None:
+            rows = [[int(x) for x in line.split()] for line in text.strip().splitlines()]
+            return cls(rows, _NCBI_ORDER, name=name)
         try:
-            text = _TABLES[name]
-        except KeyError:
-            raise ValueError(f"unknown scoring matrix: {name!r}") from None
-        rows = [[int(x) for x in line.split()] for line in text.strip().splitlines()]
-        return cls(rows, _NCBI_ORDER, name=name)
+            import scoring_matrices  # the reference's own provider, if present
+        except ImportError:
+            scoring_matrices = None
+        if scoring_matrices is not None:
+            try:
+                theirs = scoring_matrices.ScoringMatrix.from_name(name)
+            except ValueError:
+                theirs = None
+            if theirs is not None:
+                return cls([list(row) for row in theirs.matrix], str(theirs.alphabet), name=name)
+        import os
+        for directory in filter(None, os.environ.get("PYOPAL_AMD_MATRIX_PATH", "").split(os.pathsep)):
+            try:
+                entries = os.listdir(directory)
+            except OSError:
+                continue
+            wanted = {name.lower(), name.lower() + ".txt", name.lower() + ".mat"}
+            for entry in sorted(entries):
+                if entry.lower() in wanted:
+                    return cls.from_file(os.path.join(directory, entry), name=name)
+        known = " (a name of the scoring-matrices package)" if name.upper() in _KNOWN_ELSEWHERE else ""
+        raise ValueError(
+            f"unknown scoring matrix: {name!r}{known}; built in: {', '.join(sorted(_TABLES))}. Load an "
+            "NCBI-format table with ScoringMatrix.from_file(path), put it in a directory listed in "
+            "PYOPAL_AMD_MATRIX_PATH, or install scoring-matrices")
 
     @classmethod
     def from_file(cls, file, name: typing.Optional[str] = None) -> "ScoringMatrix":

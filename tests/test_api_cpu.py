@@ -243,3 +243,27 @@ def test_public_names():
     assert sorted(pyopal.__all__) == sorted(
         ["Alphabet", "Aligner", "BaseDatabase", "Database", "ScoreResult", "EndResult", "FullResult", "align"])
     assert pyopal.lib.Aligner is pyopal.Aligner and isinstance(pyopal.__version__, str)
+
+
+def test_matrix_names_beyond_the_built_in_tables(tmp_path, monkeypatch):
+    # src/pyopal/tests/test_aligner.py:10-18 builds Aligner("VTML80") through scoring-matrices,
+    # whose tables are not in the reference tree: here the name resolves from a user-supplied NCBI
+    # file, and fails with a message that says how to supply one otherwise
+    from pyopal_amd.matrices import ScoringMatrix
+    monkeypatch.delenv("PYOPAL_AMD_MATRIX_PATH", raising=False)
+    with pytest.raises(ValueError, match="from_file"):
+        ScoringMatrix.from_name("VTML80")
+    with pytest.raises(ValueError, match="scoring-matrices"):
+        pyopal.Aligner("VTML80")
+    b62 = ScoringMatrix.from_name("BLOSUM62")
+    letters = b62.alphabet
+    lines = ["# a stand-in table under another name", "   " + "  ".join(letters)]
+    for letter, row in zip(letters, b62.matrix):
+        lines.append(letter + " " + " ".join(str(int(x) + (1 if letter == "W" else 0)) for x in row))
+    (tmp_path / "vtml80.mat").write_text("\n".join(lines) + "\n")
+    monkeypatch.setenv("PYOPAL_AMD_MATRIX_PATH", str(tmp_path))
+    m = ScoringMatrix.from_name("VTML80")
+    assert m.alphabet == letters and m.is_integer() and m.name == "VTML80"
+    assert m[letters.index("W"), letters.index("W")] == 12
+    aligner = pyopal.Aligner("VTML80")
+    assert aligner.scoring_matrix == m and aligner.alphabet == pyopal.Alphabet(letters)
