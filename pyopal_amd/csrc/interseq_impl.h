@@ -896,7 +896,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
     if (threadIdx.x < 4) simdTaken[threadIdx.x] = 0;
     __syncthreads();
 
-    const int wave = threadIdx.x >> 6;
+    // (wave-uniform by construction; said so, or everything derived from it would sit in VGPRs)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int kTier[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
     const int tier = kTier[wave & 3][wave >> 2];
     const int firstDynamic = kPairWaves * gridDim.x;
