@@ -1586,6 +1586,10 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 // traceback in batches of whole direction slots and whole wavefronts of 64 pairs
                 int64_t batch =
                     std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
+                const int64_t opsCap = n * slotOps;
+                const bool overlapOps = opsCap <= (512ll << 20) && !getenv("MIOPAL_NO_OPS_OVERLAP");
+                if (overlapOps && n >= 4 * 65536)
+                    batch = std::min(batch, std::max<int64_t>(65536, (n / 4 + kLanes - 1) / kLanes * kLanes));
                 void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
                 // Direction pass: one lane per pair needs ~64 x fewer instructions per cell but a
                 // lane walks its whole window alone (strips x columns x 64 rows, ~0.4 us per strip
@@ -1630,11 +1634,52 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 }
                 RC_TRY(ws->get(kOps, (size_t)(batch * slotOps), &pslots));
                 RC_TRY(ws->get(kTraceScore, (size_t)n * sizeof(int32_t), &pts));
+                // Operations leave for the host batch by batch, on the side stream, while the next batch
+                // is computed: at least four batches when there are enough pairs to fill the chip with
+                // each (the copy of the last batch is all that is not hidden). They are staged in
+                // pinned memory, contiguously, and copied out once the total is known.
                 const int64_t nBatches = (n + batch - 1) / batch;
+                struct Events {
+                    std::vector<hipEvent_t> ev;
+                    ~Events() {
+                        for (hipEvent_t e : ev)
+                            if (e) (void)hipEventDestroy(e);
+                    }
+                } batchDone;
+                size_t opsBase = 0;
+                int64_t opsFetched = 0;
+                int64_t* fetchedTotal = nullptr;   // pinned: running total read back per batch
+                if (overlapOps) {
+                    RC_TRY(ws->ensureAux());
+                    batchDone.ev.assign((size_t)nBatches, nullptr);
+                    for (auto& e : batchDone.ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    // room for the operations, the running totals and the small per-target arrays that
+                    // follow, reserved in one go (a later drain would reset the staging buffer)
+                    const size_t head = 256 + (((size_t)nBatches * 8 + 255) & ~(size_t)255);
+                    RC_TRY(ws->reserveStaging(head + (size_t)opsCap + 256 + (size_t)n * 20 + 4096));
+                    fetchedTotal = (int64_t*)((char*)ws->pinned + ws->pinnedUsed);
+                    opsBase = ws->pinnedUsed + head;
+                    ws->pinnedUsed = opsBase + (((size_t)opsCap + 255) & ~(size_t)255);
+                }
                 void *pblock, *ptotals;
                 RC_TRY(ws->get(kOpsOff, (size_t)((batch + 255) / 256) * sizeof(int64_t), &pblock));
                 RC_TRY(ws->get(kOpsTotals, (size_t)(nBatches + 1) * sizeof(int64_t), &ptotals));
                 HIP_TRY(hipMemsetAsync(ptotals, 0, sizeof(int64_t), stream));
+                // batch b's compacted operations: wait for its gather on the side stream, read the
+                // running total, start the copy of its share
+                auto fetchOps = [&](int64_t b) -> int {
+                    HIP_TRY(hipStreamWaitEvent(ws->aux, batchDone.ev[(size_t)b], 0));
+                    HIP_TRY(hipMemcpyAsync(fetchedTotal + b, (const int64_t*)ptotals + b + 1, sizeof(int64_t),
+                                           hipMemcpyDeviceToHost, ws->aux));
+                    HIP_TRY(hipStreamSynchronize(ws->aux));
+                    const int64_t upTo = fetchedTotal[b];
+                    if (upTo < opsFetched || upTo > opsCap) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
+                    if (upTo > opsFetched)
+                        HIP_TRY(hipMemcpyAsync((char*)ws->pinned + opsBase + opsFetched, (const char*)pcompact + opsFetched,
+                                               (size_t)(upTo - opsFetched), hipMemcpyDeviceToHost, ws->aux));
+                    opsFetched = upTo;
+                    return 0;
+                };
                 for (int64_t b0 = 0, b = 0; b0 < n; b0 += batch, ++b) {
                     const int nb = (int)std::min<int64_t>(batch, n - b0);
                     PairJob* jobs = (PairJob*)pjobs + b0;
@@ -1698,7 +1743,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     HIP_TRY(launchGatherOps(nb, (const uint8_t*)pslots, slotOps, (const int32_t*)plen + b0,
                                             (int64_t*)pblock, (const int64_t*)ptotals + b, (int64_t*)ptotals + b + 1,
                                             (uint8_t*)pcompact, stream));
+                    if (overlapOps) {
+                        HIP_TRY(hipEventRecord(batchDone.ev[(size_t)b], stream));
+                        if (b > 0) RC_TRY(fetchOps(b - 1));   // batch b is queued behind it: the GPU stays busy
+                    }
                 }
+                if (overlapOps) RC_TRY(fetchOps(nBatches - 1));
                 pt.mark("traceback batches (enqueued)");
                 // results back to the host: the small arrays first (they carry the total size),
                 // the operations while the host turns lengths into offsets
@@ -1717,7 +1767,13 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 pt.mark("device pipeline + small D2H");
                 if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
                 if (!outOps->resize((size_t)total)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
-                RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
+                if (overlapOps) {
+                    // already in pinned memory (finishDownloads above waited for the side stream too)
+                    if (opsFetched != total) return fail(MIOPAL_ERR_INTERNAL, "operation count changed");
+                    Workspace::copyOut(outOps->data, (const char*)ws->pinned + opsBase, (size_t)total);
+                } else {
+                    RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
+                }
                 outOff[0] = 0;
                 for (int64_t k = 0; k < n; ++k) outOff[k + 1] = outOff[k] + lens[(size_t)k];
                 if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
