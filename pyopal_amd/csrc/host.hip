@@ -1109,7 +1109,16 @@ struct Search {
             RC_TRY(ws->get(kCounter, sizeof(int32_t), &ct));
             RC_TRY(ws->stageUpload(pp, prof.data(), prof.size() * sizeof(prof[0]), stream));
             // lanes can only leave the exact range when min(Q, L) * maxScore reaches the limit
-            const int64_t reach = (int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0);
+            // (also bounded by the query itself: every residue is aligned at most once, at best with
+            // its most favourable partner - 280 for the 53-aa README query under BLOSUM62, where
+            // Q * max(S) says 583)
+            int64_t queryBest = 0;
+            for (int i = 0; i < Q; ++i) {
+                int rowMax = 0;
+                for (int t = 0; t < A; ++t) rowMax = std::max(rowMax, matrix[query[i] * A + t]);
+                queryBest += rowMax;
+            }
+            const int64_t reach = std::min<int64_t>((int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0), queryBest);
             const int64_t limit = biased ? biasedLimit : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
