@@ -79,7 +79,7 @@ struct PhaseTimer {
 };
 
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
-constexpr int64_t kDirBudget = 2ll << 30;  // bytes of direction workspace per traceback batch
+constexpr int64_t kDirBudget = 2ll << 30;  // direction workspace: 2 x this per device-resident traceback batch, 1 x per host-built batch
 constexpr int64_t kInt32Safe = 1ll << 29;
 constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
 // A lane that owns a whole target walks its columns one after the other (about 0.8 us per
@@ -266,6 +266,8 @@ struct Workspace {
             size_t want = bytes + bytes / 8 + 256;
             HIP_TRY(hipMalloc(&buf[slot], want));
             cap[slot] = want;
+            if (want > (512u << 20) && getenv("MIOPAL_VERBOSE"))
+                fprintf(stderr, "miopal: workspace slot %d grows to %zu MiB\n", slot, want >> 20);
         }
         *out = buf[slot];
         return 0;
@@ -289,6 +291,8 @@ struct Workspace {
             return false;
         }
         cap[slot] = bytes;
+        if (bytes > (512u << 20) && getenv("MIOPAL_VERBOSE"))
+            fprintf(stderr, "miopal: workspace slot %d grows to %zu MiB\n", slot, bytes >> 20);
         *out = buf[slot];
         return true;
     }
@@ -1592,13 +1596,15 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
             const bool fits = n * slotOps <= (16ll << 30);  // else: host-built batches below
             if (fits) {
                 RC_TRY(ws->get(kCompactOps, (size_t)(n * slotOps), &pcompact));
-                // traceback in batches of whole direction slots and whole wavefronts of 64 pairs
-                int64_t batch =
-                    std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 4 / slotDir) / kLanes * kLanes);
+                // traceback in batches of whole direction slots and whole wavefronts of 64 pairs: at most
+                // 4 GB of directions per batch (the lane-per-pair layout packs two cells per byte)
+                auto batchFor = [&](int64_t slotBytes) {
+                    return std::max<int64_t>(kLanes, std::min<int64_t>(n + kLanes - 1, kDirBudget * 2 / slotBytes) / kLanes * kLanes);
+                };
+                const int64_t batchLane = batchFor(std::max<int64_t>(slotDir / 2, 1)), batchWave = batchFor(slotDir);
+                int64_t batch = batchLane;
                 const int64_t opsCap = n * slotOps;
                 const bool overlapOps = opsCap <= (512ll << 20) && !getenv("MIOPAL_NO_OPS_OVERLAP");
-                if (overlapOps && n >= 4 * 65536)
-                    batch = std::min(batch, std::max<int64_t>(65536, (n / 4 + kLanes - 1) / kLanes * kLanes));
                 void *pd, *pslots, *pbins = nullptr, *psorted = nullptr;
                 // Direction pass: one lane per pair needs ~64 x fewer instructions per cell but a
                 // lane walks its whole window alone (strips x columns x 64 rows, ~0.4 us per strip
@@ -1606,14 +1612,17 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 // targets) a wavefront per pair is done sooner. Rough cost of either, in ms:
                 bool traceLanePerPair = lanePerPair;
                 if (lanePerPair) {
-                    const double batches = std::ceil((double)n / (double)batch);
-                    const double pairs = (double)std::min<int64_t>(batch, n);
                     const double cells = (double)windowStrips * (double)(maxWindow + kLanes - 1);
-                    const double perLane = batches * std::ceil(pairs / kLanes / 2048.0) * cells * (64 * 21 * 4.5) / 2.4e6;
-                    const double perWave =
-                        batches * std::max(pairs * cells * 225.0 / (1024 * 2.4e6), cells * 250.0 / 2.4e6);
+                    const double pairsL = (double)std::min<int64_t>(batchLane, n), pairsW = (double)std::min<int64_t>(batchWave, n);
+                    const double perLane = std::ceil((double)n / (double)batchLane) * std::ceil(pairsL / kLanes / 2048.0) *
+                                           cells * (64 * 21 * 4.5) / 2.4e6;
+                    const double perWave = std::ceil((double)n / (double)batchWave) *
+                                           std::max(pairsW * cells * 225.0 / (1024 * 2.4e6), cells * 250.0 / 2.4e6);
                     traceLanePerPair = perLane <= perWave;
                 }
+                batch = traceLanePerPair ? batchLane : batchWave;
+                if (overlapOps && n >= 4 * 65536)
+                    batch = std::min(batch, std::max<int64_t>(65536, (n / 4 + kLanes - 1) / kLanes * kLanes));
                 if (pt.on)
                     fprintf(stderr, "[miopal]   traceback: longest window %lld columns, %lld strip(s) of rows, %lld pairs per batch, %s per pair\n",
                             (long long)maxWindow, (long long)windowStrips, (long long)batch,
@@ -1623,7 +1632,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 int64_t maxHead = 0;
                 void *phead = nullptr, *pheadDirs = nullptr;
                 if (sortJobs && !getenv("MIOPAL_NO_HYBRID_TRACE")) {
-                    maxHead = std::min<int64_t>((2ll << 30) / slotDir / kLanes, (batch + kLanes - 1) / kLanes);
+                    maxHead = std::min<int64_t>((1ll << 30) / slotDir / kLanes, (batch + kLanes - 1) / kLanes);
                     if (maxHead > 0) {
                         RC_TRY(ws->get(kHeadWaves, sizeof(int), &phead));
                         if (!ws->tryGet(kHeadDirs, (size_t)(maxHead * kLanes * slotDir), &pheadDirs)) maxHead = 0;
