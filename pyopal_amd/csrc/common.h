@@ -42,6 +42,7 @@ struct InterseqArgs {
     int priorityChunks;        // groups with more chunks than this raise their wave priority
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
+    int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
@@ -163,7 +164,8 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols);
 enum PairFlavour : int {
     kPairSwInt16 = 0,   // saturating int16
     kPairSwHalf = 1,    // packed half floats, exact below 2048
-    kPairSwBiased = 2   // biased integer halves compared as half floats, column-shifted (interseq_impl.h)
+    kPairSwBiased = 2,  // biased integer halves compared as half floats, column-shifted (interseq_impl.h)
+    kPairGlobalBiased = 3  // NW / HW / OV on the same representation (scores, optional end locations)
 };
 // limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
 constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
@@ -182,6 +184,10 @@ hipError_t launchInterseqPairSwBiasedA(const InterseqArgs& a, int rows, int comp
 hipError_t launchInterseqPairSwBiasedB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedLocC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

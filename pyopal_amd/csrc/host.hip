@@ -753,6 +753,7 @@ struct Search {
     int64_t n;
     int maxScore = 0, minScore = 0;
     int64_t balancedChunks = 0;
+    bool globalPairRefused = false;   // the pair-table launch for NW / HW / OV failed on this device
 
     uint8_t* d_query = nullptr;
     int32_t* d_matrix = nullptr;
@@ -1053,7 +1054,22 @@ struct Search {
                                    (int64_t)std::min<int64_t>(Q, db->maxLen) * std::max(maxScore, 0) < 60000;
             InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
             int profileShift = 0;
-            if (!sw) {
+            // One-strip NW / HW / OV: the pair-table kernel on biased integer halves (interseq_impl.h).
+            // The true values around a pattern's zero are bounded by the query, not by the targets'
+            // lengths, so no target is redone at 32 bit; the bounds are static:
+            //   below zero: 3 open + (Q + 4) ext + |min S|,   above: Q (max S + ext) + the rebase shift
+            const int64_t globalZero = 0x0400 + 3 * (int64_t)open + ((int64_t)Q + 4) * ext + std::max(0, -minScore);
+            const bool globalPair =
+                !sw && nStrips == 1 && !globalPairRefused && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
+                interseqPairFits(pairRows, nSym) && minScore > kBiasedPad && (r.topGap ? open >= ext : true) &&
+                5 * (int64_t)ext <= kLocMaxShift &&
+                globalZero + (int64_t)Q * (std::max(maxScore, 0) + ext) + kLocMaxShift + 5 * (int64_t)ext +
+                        std::max(maxScore, 0) < 0x7C00;
+            if (globalPair) {
+                // only empty targets (closed forms of the border) are left to the int32 kernel
+                for (int e = view->nPacked - 1; e >= firstPos && dbLen(db, view->ids[e]) == 0; --e)
+                    jobs.push_back(forwardJob(view->ids[e], rules));
+            } else if (!sw) {
                 const int64_t pos = std::max(maxScore, 0);
                 auto fitsPlain = [&](int64_t L) {
                     return L > 0 && 3 * (int64_t)open + (Q + L) * ext < 32000 && std::min<int64_t>(Q, L) * pos < 32000;
@@ -1087,7 +1103,7 @@ struct Search {
                 memcpy(&bits, &h, sizeof bits);
                 return bits;
             };
-            const int16_t padValue = biased ? (int16_t)kBiasedPad : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
+            const int16_t padValue = (biased || globalPair) ? (int16_t)kBiasedPad : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
                 for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t] + profileShift);
@@ -1153,6 +1169,7 @@ struct Search {
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
             ia.biasedLimit = biasedLimit;
+            ia.biasedZero = (int)globalZero;
             ia.boundaryOff = view->d_boundaryOff;
             ia.priorityChunks = getenv("MIOPAL_NO_PRIORITY") ? INT32_MAX : (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
             if ((nStrips + waves - 1) / waves > 1) {
@@ -1171,7 +1188,7 @@ struct Search {
                 HIP_TRY(hipEventRecord(e0, stream));
             }
             g_lastRouting[1] = 1;  // general kernel
-            if (usePair) {
+            if (usePair || globalPair) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
@@ -1191,15 +1208,21 @@ struct Search {
                     const bool uniform = (int64_t)shortest * 5 >= (int64_t)longest * 4;
                     ia.tailThrottle = (tt ? tt[0] == '1' : uniform) ? (ia.nGroups + blocks * 4 - 1) / (blocks * 4) : 0;
                 }
-                const PairFlavour pf = biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
+                const PairFlavour pf = globalPair ? kPairGlobalBiased : biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
                 g_lastRouting[1] = 2 + (int)pf;
                 // the biased kernel exists for every even number of rows: no padding rows to 8
-                const hipError_t pe = launchInterseqPair(ia, biased ? pairRows : rows, pf, pairUnits, stream, locate);
+                const hipError_t pe = launchInterseqPair(ia, (biased || globalPair) ? pairRows : rows, pf, pairUnits, stream, locate);
                 if (pe != hipSuccess) {
                     // e.g. the runtime refuses 150 KB of dynamic LDS: use the v_perm variant (the
                     // biased profile is a plain int16 profile whose padding score, -1024, cannot raise
                     // a Smith-Waterman maximum either)
                     (void)hipGetLastError();
+                    if (globalPair) {
+                        // (its profile and its routing of long targets do not suit the general kernel:
+                        // start over without it)
+                        globalPairRefused = true;
+                        return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
+                    }
                     g_lastRouting[1] |= 16;
                     if (getenv("MIOPAL_VERBOSE"))
                         fprintf(stderr, "miopal: pair-table kernel refused (%s), using the general kernel\n",

@@ -34,8 +34,15 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols) {
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream, bool locate) {
     if (a.nGroups <= 0) return hipSuccess;
-    if (locate && flavour != kPairSwBiased) return hipErrorInvalidValue;
+    if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased) return hipErrorInvalidValue;
     switch (flavour) {
+        case kPairGlobalBiased:
+            // (end locations are a run-time option of this kernel: a.endI != nullptr)
+            if (rowsPerStrip < 2 || rowsPerStrip > 64 || (rowsPerStrip & 1)) return hipErrorInvalidValue;
+            if (rowsPerStrip < 18) return launchInterseqPairGlobalA(a, rowsPerStrip, computeUnits, stream);
+            if (rowsPerStrip < 34) return launchInterseqPairGlobalB(a, rowsPerStrip, computeUnits, stream);
+            if (rowsPerStrip < 50) return launchInterseqPairGlobalC(a, rowsPerStrip, computeUnits, stream);
+            return launchInterseqPairGlobalD(a, rowsPerStrip, computeUnits, stream);
         case kPairSwBiased:
             // any even number of rows
             if (rowsPerStrip < 2 || rowsPerStrip > 64 || (rowsPerStrip & 1)) return hipErrorInvalidValue;

@@ -1110,6 +1110,287 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
     return hipErrorInvalidValue;
 }
 
+// ---- one-strip NW / HW / OV on biased integer halves, column-shifted --------------
+// The pair-table kernel for the modes without a floor (round 2). Same representation as above - a
+// half holds zero + x + sigma(j) and is compared as a half float, additions are 32-bit integer adds,
+// values of column j carry sigma(j) = j * ext so that extending E is free - with what the other
+// modes need:
+//  * borders: H[-1][j], H[i][-1] = 0 or the gap of j + 1 / i + 1 residues (borderGap), entered per
+//    column as wave-uniform patterns;
+//  * no floor: E = max(E, hmo), F = max(F, hmo) - ext; 3 integer adds + 3 max per cell pair (the
+//    general kernel's shifted int16 flavour: 6 packed operations + 1 v_perm);
+//  * the answer of a lane half is read at its own last column / on the last query row, turned into a
+//    true 32-bit value x = pattern - (zero + sigma(j)): the lanes never leave their range because of
+//    a target's length (NW scores of 35000-residue targets are far below -32768, the pattern is not),
+//    so nothing is flagged and no target is redone at 32 bit. The host checks the static bounds
+//    (zero covers 2 open + (Q + 2) ext + |min S|, Q (max S + ext) + zero + kBiasedMaxShift < 0x7C00);
+//  * with a free top border (HW, OV) x is bounded and sigma is rebased like the Smith-Waterman
+//    kernel's; with a penalised one (NW) x + j ext is bounded and sigma just grows (as an int).
+// End locations (optional): the scan rules of oracle/opal_oracle.c on those per-column values.
+// Eight wavefronts per workgroup (two per SIMD, up to 256 VGPRs): beside H[R], E[R] this kernel keeps
+// per-lane answers, lengths and locations, and hipcc's schedule of the column needs more registers
+// than the Smith-Waterman one; two wavefronts per SIMD issue within a few per cent of three
+// (profiles/r02_ubench_mix.txt).
+constexpr int kGlobalWaves = 8;
+
+template <int R>
+__global__ __launch_bounds__(kGlobalWaves * kLanes) void interseq_pair_global_kernel(InterseqArgs a) {
+    constexpr int SLOTS = PairLayout<R>::kRowSlots;
+    constexpr int NB4 = (R + 3) / 4;
+    extern __shared__ uint4 pairs[];
+
+    const int lane = threadIdx.x & 63;
+    const int nSym = a.nSymbols;
+    const int ext = a.gapExt, open = a.gapOpen, Q = a.qLen;
+    const int zero = a.biasedZero;
+    const bool topGap = a.topGap, leftGap = a.leftGap;
+    const int region = a.region;
+    const bool locate = a.endI != nullptr;
+    const uint32_t ext2 = both(ext), openMinusExt2 = both(open - ext);
+
+    // table: (s + ext) of both targets as one integer; padding symbol / rows add nothing
+    {
+        const int16_t* gp = a.profile;
+        uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
+        const int total = nSym * nSym * R;
+        for (int idx = threadIdx.x; idx < total; idx += kGlobalWaves * kLanes) {
+            const int row = idx / R, r = idx - row * R;
+            const int tA = row / nSym, tB = row - tA * nSym;
+            const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
+            const int sA = vA == kBiasedPadScore ? 0 : vA + ext;
+            const int sB = vB == kBiasedPadScore ? 0 : vB + ext;
+            pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
+        }
+    }
+    int* simdTaken = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);
+    if (threadIdx.x < 4) simdTaken[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr int kTier[4][2] = {{0, 7}, {1, 6}, {2, 5}, {3, 4}};
+    const int tier = kTier[wave & 3][wave >> 2];
+    const int firstDynamic = kGlobalWaves * gridDim.x;
+    const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
+    bool firstRound = true;
+    for (;;) {
+        int g;
+        if (firstRound) {
+            g = tier * gridDim.x + ((tier & 1) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x);
+            firstRound = false;
+            if (lane == 0 && a.tailThrottle > 0) atomicAdd(&simdTaken[simd], 1);
+            if (g >= a.nGroups) continue;
+            g += a.groupBase;
+        } else {
+            g = 0;
+            if (lane == 0) {
+                bool take = true;
+                if (a.tailThrottle > 0) take = atomicAdd(&simdTaken[simd], 1) < a.tailThrottle;
+                g = take ? atomicAdd(a.workCounter, 1) : INT32_MAX - firstDynamic;
+            }
+            g = __builtin_amdgcn_readfirstlane(g) + firstDynamic;
+            if (g >= a.nGroups) break;
+            g += a.groupBase;
+        }
+        const uint2* pack = a.pack + a.groupOff[g];
+        const int nChunks = a.groupChunks[g];
+        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        const size_t base = (size_t)g * kGroupTargets;
+        const int lenA = a.lens[base + lane], lenB = a.lens[base + kLanes + lane];
+
+        // answers (true values) and where they were found
+        int runA = INT32_MIN, runB = INT32_MIN, colA = -1, colB = -1, rowA = -1, rowB = -1;
+        int cbA = INT32_MIN, cbB = INT32_MIN, crowA = -1, crowB = -1;   // OV: best of the last column
+
+        int sigma = zero - ext;             // zero + sigma(j) of the last column done (column -1 here)
+        int shift = -ext;                   // part of sigma accumulated since the last rebase
+        uint32_t H[R], E[R];
+        {
+            // (opaque to the optimiser: the 2 R border values are the same for every group, and hoisting
+            // them out of the group loop would cost 2 R registers for the whole kernel)
+            int zeroHere = zero, openHere = open, extHere = ext;
+            asm volatile("" : "+s"(zeroHere), "+s"(openHere), "+s"(extHere));
+            // H[r][-1]: one gap of r + 1 residues or r + 1 one-residue gaps (borderGap), as running sums
+            int one = openHere, many = openHere;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int left = leftGap ? -min(one, many) : 0;
+                H[r] = both(zeroHere - extHere + left);                   // on column -1's scale
+                E[r] = both(zeroHere + left - openHere);                  // E[r][0] on column 0's scale
+                one += extHere;
+                many += openHere;
+            }
+        }
+        uint2 cur = pack[lane];
+        auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
+            const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
+            return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
+                                                  __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
+        };
+        constexpr int kWant = 3;
+        constexpr int kAhead = NB4 > kWant ? kWant : 1;
+        const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
+        uint4 vn[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+        for (int c = 0; c < nChunks; ++c) {
+            uint2 nxt = {0, 0};
+            if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+            uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+            for (int cc = 0; cc < 4; ++cc) {
+                const int j = c * 4 + cc;
+                const uint4* prow = prowNext;
+                uint4 v[NB4];
+#pragma unroll
+                for (int k = 0; k < kAhead; ++k) v[k] = vn[k];
+                ra = cc < 3 ? ra >> 8 : nxt.x;
+                rb = cc < 3 ? rb >> 8 : nxt.y;
+                prowNext = rowOf(ra & 0xffu, rb & 0xffu);
+                auto score = [&](int r) -> uint32_t {
+                    const uint4 x = v[r >> 2];
+                    const int k = r & 3;
+                    return k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                };
+                // row above the strip: H[-1][j-1] on the previous column's scale, H[-1][j] on this one's
+                const int topPrev = (j == 0 || !topGap) ? 0 : borderGap(j - 1, open, ext);
+                const int topHere = topGap ? borderGap(j, open, ext) : 0;
+                uint32_t dsum = both(sigma + topPrev) + score(0);
+                sigma += ext;
+                uint32_t f = both(sigma + topHere - open);      // F entering row 0
+                asm volatile("" : "+v"(f));
+#pragma unroll
+                for (int r4 = 0; r4 < NB4; ++r4) {
+                    if (r4 + kAhead < NB4) v[r4 + kAhead] = prow[r4 + kAhead];
+                    if (r4 == (NB4 > 3 ? NB4 - 3 : 0)) {
+#pragma unroll
+                        for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int r = r4 * 4 + k;
+                        if (r >= R) continue;
+                        uint32_t dnext = 0;
+                        if (r + 1 < R) dnext = H[r] + score(r + 1);
+                        const uint32_t h = pk_max3_f16(dsum, E[r], f);
+                        const uint32_t hmo = h - openMinusExt2;
+                        E[r] = pk_max3_f16(E[r], hmo, hmo);
+                        if (r + 1 < R) f = pk_max3_f16(f, hmo, hmo) - ext2;
+                        H[r] = h;
+                        dsum = dnext;
+                    }
+                    // pins the schedule: no ds_read and none of the NEXT blocks' diagonal sums (they only
+                    // need last column's H, all of it available at the column's top: hoisting them costs
+                    // R registers) may start before this block's cells are done
+                    asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+#pragma unroll
+                    for (int k = 1; k <= 4; ++k)
+                        if (r4 * 4 + 3 + k < R) asm volatile("" : "+v"(H[r4 * 4 + 3 + k]));
+                }
+                // ---- answers: the last query row is row R - 1 or R - 2 (R = Q rounded up to even)
+                const uint32_t hq = (Q & 1) ? H[R >= 2 ? R - 2 : 0] : H[R - 1];
+                const int qA = (int)(hq & 0xffffu) - sigma, qB = (int)(hq >> 16) - sigma;
+                if (region == kLastCell) {
+                    if (j == lenA - 1) { runA = qA; colA = j; }
+                    if (j == lenB - 1) { runB = qB; colB = j; }
+                } else {
+                    // last row: HW scans columns < len, OV columns < len - 1 (its last column is
+                    // scanned row by row below)
+                    const int cut = region == kLastRowCol ? 1 : 0;
+                    if (j < lenA - cut && qA > runA) { runA = qA; colA = j; }
+                    if (j < lenB - cut && qB > runB) { runB = qB; colB = j; }
+                    const bool lastA = j == lenA - 1, lastB = j == lenB - 1;
+                    if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastA || lastB) != 0) {
+                        // some lane is on its target's last column: first maximum over the query rows
+                        int mA = INT32_MIN, mB = INT32_MIN, ia = 0, ib = 0;
+#pragma unroll
+                        for (int r = R - 1; r >= 0; --r) {
+                            // (rows beyond the query: only row R - 1, when Q is odd; one test, not one
+                            // per row - per-row predicates would be hoisted into a hundred SGPRs)
+                            if (r == R - 1 && (Q & 1)) continue;
+                            const int hA = (int)(H[r] & 0xffffu), hB = (int)(H[r] >> 16);
+                            if (hA >= mA) { mA = hA; ia = r; }
+                            if (hB >= mB) { mB = hB; ib = r; }
+                            // (row by row: the scheduler would otherwise unpack all 2 R halves up front)
+                            asm volatile("" : "+v"(mA), "+v"(mB));
+                        }
+                        if (lastA) { cbA = mA - sigma; crowA = ia; }
+                        if (lastB) { cbB = mB - sigma; crowB = ib; }
+                    }
+                }
+            }
+            cur = nxt;
+            shift += 4 * ext;
+            if (!topGap && shift + 4 * ext > kBiasedMaxShift) {
+                const uint32_t d = both(shift);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    H[r] -= d;
+                    E[r] -= d;
+                }
+                sigma -= shift;
+                shift = 0;
+            }
+        }
+        if (region != kLastCell || true) {
+            rowA = colA >= 0 ? Q - 1 : -1;
+            rowB = colB >= 0 ? Q - 1 : -1;
+        }
+        if (region == kLastRowCol) {
+            // OV: the last column is scanned after the last row's earlier columns, strictly greater wins
+            if (crowA >= 0 && (colA < 0 || cbA > runA)) { runA = cbA; rowA = crowA; colA = lenA - 1; }
+            if (crowB >= 0 && (colB < 0 || cbB > runB)) { runB = cbB; rowB = crowB; colB = lenB - 1; }
+        }
+        a.score[base + lane] = runA;
+        a.score[base + kLanes + lane] = runB;
+        if (locate) {
+            a.endI[base + lane] = rowA;
+            a.endI[base + kLanes + lane] = rowB;
+            a.endJ[base + lane] = colA;
+            a.endJ[base + kLanes + lane] = colB;
+        }
+        if (a.overflow) {
+            a.overflow[base + lane] = 0;
+            a.overflow[base + kLanes + lane] = 0;
+        }
+    }
+}
+
+template <int R>
+static hipError_t launchPairGlobalR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;
+    static uint64_t configured = 0;
+    if (firstUseOnThisDevice(&configured)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_global_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
+    }
+    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kGlobalWaves - 1) / kGlobalWaves));
+    hipLaunchKernelGGL((interseq_pair_global_kernel<R>), dim3(blocks), dim3(kGlobalWaves * kLanes), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int kLo>
+static hipError_t launchPairGlobal(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    if (a.nStrips != 1) return hipErrorInvalidValue;
+    switch (rowsPerStrip - kLo) {
+        case 0: return launchPairGlobalR<kLo>(a, computeUnits, stream);
+        case 2: return launchPairGlobalR<kLo + 2>(a, computeUnits, stream);
+        case 4: return launchPairGlobalR<kLo + 4>(a, computeUnits, stream);
+        case 6: return launchPairGlobalR<kLo + 6>(a, computeUnits, stream);
+        case 8: return launchPairGlobalR<kLo + 8>(a, computeUnits, stream);
+        case 10: return launchPairGlobalR<kLo + 10>(a, computeUnits, stream);
+        case 12: return launchPairGlobalR<kLo + 12>(a, computeUnits, stream);
+        case 14: return launchPairGlobalR<kLo + 14>(a, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 // Bytes of LDS the pair table needs for this strip height (host-side sizing).
 static inline size_t pairTableBytes(int rowsPerStrip, int nSymbols) {
     return (size_t)nSymbols * nSymbols * (size_t)(((rowsPerStrip + 3) / 4) | 1) * 16;

@@ -49,5 +49,7 @@ def test_pair_table_kernels_keep_three_wavefronts_per_simd():
     pair = {n: k for n, k in ks.items() if "interseq_pair" in n}
     assert pair
     # kPairWaves = 12 wavefronts per workgroup, one workgroup per CU: 3 per SIMD, <= 168 VGPRs
-    low = {n: k for n, k in pair.items() if k.get("Occupancy [waves/SIMD]", 0) < 3}
+    # (the NW / HW / OV form runs 8 wavefronts per workgroup: 2 per SIMD, up to 256 VGPRs)
+    low = {n: k for n, k in pair.items()
+           if k.get("Occupancy [waves/SIMD]", 0) < (2 if "pair_global" in n else 3)}
     assert not low, low

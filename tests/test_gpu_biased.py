@@ -193,3 +193,74 @@ def test_switch_restores_the_half_float_rung(capi, monkeypatch):
         np.testing.assert_array_equal(got["score"], want["score"])
     finally:
         db.close()
+
+
+PAIR_GLOBAL = 5  # miopalLastRouting counts[1]: 2 + kPairGlobalBiased
+
+
+def check_algo(capi, algo, query, res, off, matrix, go, ge, modes=("score", "end", "full"), expect_kernel=PAIR_GLOBAL, tag=""):
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for mode in modes:
+            got = db.search(query, matrix, go, ge, mode, algo)
+            kernel = capi.DeviceDatabase.last_routing()[1]
+            want = _oracle.search(query, res, off, matrix, go, ge, mode, algo)
+            for key in want:
+                if key == "aln":
+                    for k, (a, b) in enumerate(zip(got[key], want[key])):
+                        assert a.tolist() == b.tolist(), f"{tag} {algo} {mode} alignment {k}"
+                else:
+                    np.testing.assert_array_equal(got[key], want[key], err_msg=f"{tag} {algo} {mode} {key}")
+            if expect_kernel is not None:
+                assert kernel == expect_kernel, f"{tag} {algo} {mode}: lane-per-target pass ran kernel {kernel}"
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
+@pytest.mark.parametrize("qlen", [1, 2, 3, 7, 8, 16, 17, 31, 32, 33, 52, 53, 54, 59, 60])
+def test_global_modes_every_kind_of_strip(capi, algo, qlen):
+    # one-strip NW / HW / OV on the pair-table kernel: odd and even query lengths (the last query row
+    # is row R - 1 or R - 2), ragged groups, empty and one-residue targets, related targets
+    rng = np.random.default_rng(2000 + qlen)
+    query = _data.random_protein(rng, qlen)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(0, 150, size=300)]
+    seqs += [np.concatenate([_data.random_protein(rng, int(rng.integers(0, 30))), _data.mutate(rng, query, 0.1),
+                             _data.random_protein(rng, int(rng.integers(0, 30)))]) for _ in range(20)]
+    seqs += [_data.random_protein(rng, 1), np.zeros(0, np.uint8), query.copy()]
+    res, off = _oracle.flatten(seqs)
+    check_algo(capi, algo, query, res, off, B62, 3, 1, tag=f"Q={qlen}")
+
+
+@pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
+@pytest.mark.parametrize("go,ge", [(11, 1), (1, 1), (5, 0), (0, 0), (14, 12), (2, 5), (40, 12)])
+def test_global_modes_gap_models(capi, algo, go, ge):
+    rng = np.random.default_rng(go * 100 + ge + 7)
+    query = _data.random_protein(rng, 47)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 300, size=300)]
+    seqs += [_data.mutate(rng, query, 0.2) for _ in range(30)]
+    res, off = _oracle.flatten(seqs)
+    # (NW with open < ext, and gap costs beyond the static bounds, take the general kernel: no kernel check)
+    check_algo(capi, algo, query, res, off, B62, go, ge, modes=("score", "end"), expect_kernel=None, tag=f"gap {go}/{ge}")
+
+
+@pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
+def test_global_modes_no_target_leaves_the_lanes_for_its_length(capi, algo):
+    # gap 70/60: (Q + L) ext passes 32000 at L = 480, the general kernel's int16 lanes would hand the
+    # longer targets to the int32 kernel; here a pattern carries zero + j ext and the true value is
+    # read as a 32-bit number, so everything stays in the lanes. HW / OV rebase their shift every
+    # 68 columns at this ext.
+    rng = np.random.default_rng(91)
+    query = _data.random_protein(rng, 53)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(380, 512, size=300)]
+    seqs[3] = np.concatenate([seqs[3][:200], _data.mutate(rng, query, 0.05), seqs[3][200:330]])
+    res, off = _oracle.flatten(seqs)
+    check_algo(capi, algo, query, res, off, B62, 70, 60, modes=("score", "end"), tag="gap 70/60")
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(query, B62, 70, 60, "score", algo)["score"]
+        assert capi.DeviceDatabase.last_routing()[0] == 0   # nothing on the int32 kernel
+        if algo == "nw":
+            assert got.min() < -20000
+    finally:
+        db.close()
