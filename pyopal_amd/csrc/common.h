@@ -41,6 +41,10 @@ struct InterseqArgs {
     uint8_t* overflow;         // [nGroups * 128], 1 = lane reached the flavour's limit (may be null)
     int priorityChunks;        // groups with more chunks than this raise their wave priority
     int* workCounter;          // zeroed before launch: next group to hand out (persistent kernels)
+    // unit mode of the general kernel (scores, several rounds of strips; null: a workgroup per group)
+    int* unitCounter;          // zeroed before the launch: next (round, group) unit
+    int* unitFlags;            // [nGroups], zeroed: rounds of the group that are complete
+    uint2* unitPartial;        // [nGroups][W][64]: {all-cells best, region answer} carried between rounds
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)

@@ -146,7 +146,7 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kUnitState, kUnitPartial, kSlots
 };
 
 struct Workspace {
@@ -1179,6 +1179,25 @@ struct Search {
                 RC_TRY(ws->get(kBoundary1, bytes, &b1));
                 ia.boundary[0] = (uint2*)b0;
                 ia.boundary[1] = (uint2*)b1;
+            }
+            // several rounds of strips per group, scores only: (group, round) units instead of one
+            // workgroup per group (interseq_impl.h, "unit mode")
+            // Only when the groups are few for the chip (under six workgroup-lifetimes): the rounds of
+            // a group are then far apart in time and its boundary rows come back from HBM, not from
+            // the caches (500k x 300 at Q = 300, 7.6 lifetimes: 6.6 ms classic, 7.0 ms in units;
+            // 100k x 2000 at Q = 2000, 3.05 lifetimes: 66 ms classic, 55 ms in units).
+            const int64_t unitSlots = (int64_t)db->computeUnits * std::max(1, 8 / waves);
+            const char* um = getenv("MIOPAL_UNITS");
+            const bool wantUnits = um ? um[0] == '1' : (int64_t)(view->nGroups - firstGroup) < 6 * unitSlots;
+            if ((nStrips + waves - 1) / waves > 1 && !locate && !usePair && !globalPair && wantUnits) {
+                void *us, *up;
+                const size_t ints = (size_t)ia.nGroups + 1;
+                RC_TRY(ws->get(kUnitState, ints * sizeof(int), &us));
+                RC_TRY(ws->get(kUnitPartial, (size_t)ia.nGroups * waves * kLanes * sizeof(uint2), &up));
+                HIP_TRY(hipMemsetAsync(us, 0, ints * sizeof(int), stream));
+                ia.unitCounter = (int*)us;
+                ia.unitFlags = (int*)us + 1;
+                ia.unitPartial = (uint2*)up;
             }
             const bool timed = db->profiling.load() != 0;
             hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -193,10 +193,11 @@ static __device__ __forceinline__ uint32_t selectHalves(uint32_t dst, uint32_t v
 // LOC = true: also report where the answer was found (OPAL_SEARCH_SCORE_END): the
 // first maximum when candidates are visited target column by target column and,
 // inside a column, query row by query row (oracle/opal_oracle.c).
-template <int R, typename Arith, int W, bool TRACK_ALL, bool MULTI, bool LOC>
+template <int R, typename Arith, int W, bool TRACK_ALL, bool MULTI, bool LOC, bool UNITS = false>
 __global__ __launch_bounds__(W * kLanes)
 void interseq_kernel(InterseqArgs a) {
     static_assert(MULTI || W == 1, "a single strip needs a single wavefront");
+    static_assert(!UNITS || (MULTI && !LOC), "unit mode: scores of multi-strip queries");
     constexpr int kLowInt = Arith::kFloor ? 0 : INT32_MIN;
     static_assert(!(Arith::kDiag && TRACK_ALL), "the shifted flavour has no all-cells maximum");
     constexpr bool kRegions = !Arith::kFloor;  // Smith-Waterman flavours only know the all-cells maximum
@@ -210,16 +211,47 @@ void interseq_kernel(InterseqArgs a) {
 
     const int wave = W > 1 ? (int)(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x + a.groupBase;  // one group of 128 targets per workgroup
+    const int nStrips = MULTI ? a.nStrips : 1;
+    const int nRounds = (nStrips + W - 1) / W;
+    // Unit mode (scores only, several rounds of strips per group): a workgroup does not own a group
+    // for all its rounds but takes (group, round) units from a counter, rounds in order. The rounds
+    // of a group already hand their last row over through HBM; a group of a 2000-residue query is
+    // 4 rounds, and 782 such groups on 256 resident workgroups are 3.05 workgroup-lifetimes, i.e. 4:
+    // with units of one round the last quarter of the launch is no longer three quarters idle.
+    // The few answers a wavefront carries from round to round travel through a.unitPartial.
+    __shared__ int ldsUnit;
+    // (a template parameter: the extra scalars it keeps alive cost the classic form 5 % when both
+    // shared one instantiation)
+    constexpr bool unitMode = UNITS;
+    int unitRound = 0;
+next_unit:
+    int groupIndex = blockIdx.x;
+    if (unitMode) {
+        if (threadIdx.x == 0) ldsUnit = atomicAdd(a.unitCounter, 1);
+        __syncthreads();
+        const int u = ldsUnit;
+        __syncthreads();
+        if (u >= a.nGroups * nRounds) return;
+        groupIndex = u % a.nGroups;     // rounds in order: round r of every group before round r + 1 of any
+        unitRound = u / a.nGroups;
+        if (unitRound > 0) {
+            // the round before this one, done by whoever took that unit (earlier than this one)
+            if (threadIdx.x == 0)
+                while (__hip_atomic_load(a.unitFlags + groupIndex, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < unitRound)
+                    __builtin_amdgcn_s_sleep(4);
+            __syncthreads();
+        }
+    }
+    const int g = groupIndex + a.groupBase;  // one group of 128 targets per workgroup (and unit)
 
     uint4* prof = ldsProf[wave];
     const uint2* pack = a.pack + a.groupOff[g];
     const int nChunks = a.groupChunks[g];
     if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);  // long group: critical path
+    else if (unitMode) __builtin_amdgcn_s_setprio(0);
     const Arith ar(a.gapOpen, a.gapExt);
     const uint4* gprof = reinterpret_cast<const uint4*>(a.profile);
     const int rowSlotsGlobal = a.qPad / 8;
-    const int nStrips = MULTI ? a.nStrips : 1;
     const int Q = a.qLen;
     const bool topGap = a.topGap, leftGap = a.leftGap;
     const int region = kRegions ? a.region : (int)kAllCells;
@@ -257,10 +289,15 @@ void interseq_kernel(InterseqArgs a) {
 
     const int lastStrip = nStrips - 1;
     const int rl = Q - 1 - lastStrip * R;  // row of the last query residue inside the last strip
-    const int nRounds = (nStrips + W - 1) / W;
     const int nSteps = nChunks + (W - 1);
+    if (unitMode && unitRound > 0) {
+        // what this wavefront's strips of the earlier rounds found
+        const uint2 p = a.unitPartial[((size_t)groupIndex * W + wave) * kLanes + lane];
+        best = p.x;
+        ans = p.y;
+    }
 
-    for (int rho = 0; rho < nRounds; ++rho) {
+    for (int rho = unitMode ? unitRound : 0; rho < (unitMode ? unitRound + 1 : nRounds); ++rho) {
         const int s = rho * W + wave;
         const bool active = s < nStrips;
         const bool isLast = s == lastStrip;
@@ -581,20 +618,35 @@ void interseq_kernel(InterseqArgs a) {
         }
         return;
     }
-    uint32_t res = (TRACK_ALL && region == kAllCells) ? best : ans;
-    if (W > 1) {
-        ldsOut[wave][lane] = res;
+    if (unitMode && unitRound + 1 < nRounds) {
+        // not the group's last round: leave the partial answers and the round's boundary row (HBM,
+        // fenced above) to whoever takes the next round of this group
+        a.unitPartial[((size_t)groupIndex * W + wave) * kLanes + lane] = make_uint2(best, ans);
+        __threadfence();
         __syncthreads();
-        if (wave != 0) return;
-        for (int w = 1; w < W; ++w) res = ar.max2(res, ldsOut[w][lane]);
+        if (threadIdx.x == 0)
+            __hip_atomic_store(a.unitFlags + groupIndex, unitRound + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        goto next_unit;
     }
-    const int lo = Arith::toInt(res & 0xffffu), hi = Arith::toInt(res >> 16);
-    a.score[base + lane] = lo;
-    a.score[base + kLanes + lane] = hi;
-    if (a.overflow) {
-        a.overflow[base + lane] = lo >= Arith::kLimit;
-        a.overflow[base + kLanes + lane] = hi >= Arith::kLimit;
+    {
+        uint32_t res = (TRACK_ALL && region == kAllCells) ? best : ans;
+        if (W > 1) {
+            ldsOut[wave][lane] = res;
+            __syncthreads();
+            if (wave == 0)
+                for (int w = 1; w < W; ++w) res = ar.max2(res, ldsOut[w][lane]);
+        }
+        if (wave == 0) {
+            const int lo = Arith::toInt(res & 0xffffu), hi = Arith::toInt(res >> 16);
+            a.score[base + lane] = lo;
+            a.score[base + kLanes + lane] = hi;
+            if (a.overflow) {
+                a.overflow[base + lane] = lo >= Arith::kLimit;
+                a.overflow[base + kLanes + lane] = hi >= Arith::kLimit;
+            }
+        }
     }
+    if (unitMode) goto next_unit;   // (the barriers of the hand-out keep ldsOut safe)
 }
 
 template <int R, typename Arith, bool TRACK_ALL, bool LOC>
@@ -603,6 +655,18 @@ static hipError_t launchW(const InterseqArgs& a, int waves, hipStream_t stream) 
     if (a.nStrips == 1) {
         hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, false, LOC>), grid, dim3(kLanes), 0, stream, a);
         return hipGetLastError();
+    }
+    if constexpr (!LOC) {
+        if (a.unitCounter != nullptr) {
+            switch (waves) {
+                case 1: hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, true, false, true>), grid, dim3(1 * kLanes), 0, stream, a); break;
+                case 2: hipLaunchKernelGGL((interseq_kernel<R, Arith, 2, TRACK_ALL, true, false, true>), grid, dim3(2 * kLanes), 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((interseq_kernel<R, Arith, 4, TRACK_ALL, true, false, true>), grid, dim3(4 * kLanes), 0, stream, a); break;
+                case 8: hipLaunchKernelGGL((interseq_kernel<R, Arith, 8, TRACK_ALL, true, false, true>), grid, dim3(8 * kLanes), 0, stream, a); break;
+                default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
     }
     switch (waves) {
         case 1: hipLaunchKernelGGL((interseq_kernel<R, Arith, 1, TRACK_ALL, true, LOC>), grid, dim3(1 * kLanes), 0, stream, a); break;

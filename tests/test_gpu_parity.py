@@ -439,6 +439,26 @@ def test_strip_configurations(capi, monkeypatch, config):
             compare(gpu, ref, "end", f"strips {config or 'default'} {algo} Q={qlen}")
 
 
+@pytest.mark.parametrize("config", ["4,4", "4,2", "4,1", "8,4", "8,2", "6,2", "5,1", "16,8", "12,4"])
+def test_unit_mode_of_multi_round_score_searches(capi, monkeypatch, config):
+    """Scores of queries whose strips take several rounds: with MIOPAL_UNITS=1 a workgroup takes
+    (group, round) units from a counter instead of owning a group; boundary rows and the partial
+    answers of a wavefront travel through HBM between rounds, possibly between workgroups. Every
+    algorithm (the all-cells maximum of SW and the last-row / last-column answers of HW / OV are
+    carried across rounds), ragged groups, more units than workgroups can be resident."""
+    monkeypatch.setenv("MIOPAL_STRIPS", config)
+    monkeypatch.setenv("MIOPAL_UNITS", "1")
+    rng = np.random.default_rng(173)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=1500)]
+    for qlen in (150, 333, 700):
+        q = _data.random_protein(rng, qlen)
+        extra = [np.concatenate([_data.random_protein(rng, 40), _data.mutate(rng, q, 0.1)]) for _ in range(6)]
+        res, off = _oracle.flatten(seqs + extra)
+        for algo in ALGOS:
+            gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "score", algo)
+            compare(gpu, ref, "score", f"units {config} {algo} Q={qlen}")
+
+
 def test_segmented_view_with_lanes_leaving_the_half_float_range(capi):
     """A window whose lane saturates the first rung (scores >= 2048) is flagged like any other
     lane, and its target recomputed whole by the next rungs - over the merged window maxima."""
