@@ -159,8 +159,10 @@ enum InterseqFlavour : int {
     kSwInt16 = 1,             // Smith-Waterman, saturating int16
     kSignedInt16 = 2,         // NW / HW / OV, signed saturating int16
     kSignedInt16AllCells = 3, // anchored reverse pass: signed, every cell is a candidate
-    kSignedInt16Diag = 4      // NW / HW / OV on anti-diagonally shifted values (6 ops per cell pair)
+    kSignedInt16Diag = 4,     // NW / HW / OV on anti-diagonally shifted values (6 ops per cell pair)
+    kUnsignedDiag = 5         // the same on unsigned patterns compared as half floats (5 cheaper ops, interseq_impl.h)
 };
+constexpr int kUnsignedDiagZero = 0x1000;  // = kU16Zero
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
                           bool locate, hipStream_t stream);
 // pair-indexed LDS profile (single strip, Smith-Waterman); false = table does not fit LDS
@@ -207,6 +209,8 @@ hipError_t launchInterseqSignedLoc(const InterseqArgs& a, int rowsPerStrip, int 
 hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedDiag(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqUnsignedDiag(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqUnsignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);

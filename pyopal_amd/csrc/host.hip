@@ -1000,6 +1000,8 @@ struct Search {
             int64_t total = 0;
             for (int c : view->groupChunksHost) total += c;
             const int64_t slots = (int64_t)db->computeUnits * std::max(1, 12 / waves);
+            // (2.5 x the balanced share; measured again in round 2 on the log-normal database, NW at
+            // Q = 150: keeping the longest group in the packed kernel costs 5.6 ms against 4.0)
             int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
             // windows of a segmented view are as short as a group of long targets can get
             if (overlap > 0) limit = std::max<int64_t>(limit, (segmentStride(overlap) + overlap + 3) / 4);
@@ -1087,6 +1089,22 @@ struct Search {
                 if (diag) {
                     flavour = kSignedInt16Diag;
                     profileShift = 2 * ext;
+                    // The same shift on unsigned patterns compared as half floats (ArithU16Diag: integer
+                    // adds, one max3 for h): scores after the shift must not be negative
+                    // (s + ext + open >= 0), open >= ext, and every pattern
+                    // zero + x + (i + j) ext within [0, 0x7BFF] for the longest target that stays packed.
+                    const int64_t c = (int64_t)open - ext;
+                    const int64_t Lfit = dbLen(db, view->ids[firstFit]);
+                    const int64_t top = kUnsignedDiagZero + std::min<int64_t>(Q, Lfit) * pos + (Q + Lfit + 2) * (int64_t)ext +
+                                        pos + 2 * (int64_t)ext + c;
+                    const int64_t below = 3 * (int64_t)open + 2 * (int64_t)ext + std::max(0, -minScore) + c;
+                    if (c >= 0 && (int64_t)minScore + ext + open >= 0 && top < 0x7C00 &&
+                        0x0400 + below + 64 <= kUnsignedDiagZero &&   // real cells stay above the padding cells' floor
+
+                        !getenv("MIOPAL_NO_UNSIGNED_DIAG")) {
+                        flavour = kUnsignedDiag;
+                        profileShift = 2 * ext + (int)c;
+                    }
                 }
                 // the targets that do not fit form a prefix of the view, empty targets (closed
                 // forms of the border) a suffix; both are redone by the int32 kernel
@@ -1103,7 +1121,10 @@ struct Search {
                 memcpy(&bits, &h, sizeof bits);
                 return bits;
             };
-            const int16_t padValue = (biased || globalPair) ? (int16_t)kBiasedPad : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
+            // (the unsigned shifted flavour: padding scores open - ext after the shift, see ArithU16Diag)
+            const int16_t padValue = (biased || globalPair) ? (int16_t)kBiasedPad
+                                     : flavour == kUnsignedDiag ? (int16_t)(open - ext)
+                                     : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
             for (int t = 0; t < A; ++t)
                 for (int i = 0; i < Q; ++i) prof[(size_t)t * qPad + i] = enc(matrix[query[i] * A + t] + profileShift);

@@ -13,6 +13,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
             case kSignedInt16: return launchInterseqSignedLoc(a, rowsPerStrip, waves, stream);
             case kSignedInt16AllCells: return launchInterseqSignedAllLoc(a, rowsPerStrip, waves, stream);
             case kSignedInt16Diag: return launchInterseqSignedDiagLoc(a, rowsPerStrip, waves, stream);
+            case kUnsignedDiag: return launchInterseqUnsignedDiagLoc(a, rowsPerStrip, waves, stream);
         }
         return hipErrorInvalidValue;
     }
@@ -22,6 +23,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
         case kSignedInt16: return launchInterseqSigned(a, rowsPerStrip, waves, stream);
         case kSignedInt16AllCells: return launchInterseqSignedAll(a, rowsPerStrip, waves, stream);
         case kSignedInt16Diag: return launchInterseqSignedDiag(a, rowsPerStrip, waves, stream);
+        case kUnsignedDiag: return launchInterseqUnsignedDiag(a, rowsPerStrip, waves, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -85,6 +85,10 @@ struct ArithSwI16 {
     static constexpr bool kFloor = true;    // Smith-Waterman
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // a best at or above this may have clipped
+    static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
+    static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
+    static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t) const { return v; }
     uint32_t open2, ext2;
     __device__ __forceinline__ ArithSwI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
     __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
@@ -106,6 +110,10 @@ struct ArithSwF16 {
     static constexpr bool kFloor = true;
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 2048;
+    static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
+    static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
+    static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t) const { return v; }
     uint32_t negOpen2, negExt2;
     static __device__ __forceinline__ uint32_t pack(int v) {
         const _Float16 h = (_Float16)(float)v;
@@ -134,6 +142,10 @@ struct ArithI16 {
     static constexpr bool kFloor = false;   // NW / HW / OV / anchored reverse pass
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // ranges are checked statically by the host
+    static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
+    static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
+    static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t) const { return v; }
     uint32_t open2, ext2;
     __device__ __forceinline__ ArithI16(int open, int ext) : open2(dup16(min(open, 32767))), ext2(dup16(min(ext, 32767))) {}
     __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
@@ -160,6 +172,11 @@ struct ArithI16Diag {
     static constexpr bool kFloor = false;
     static constexpr bool kDiag = true;
     static constexpr int kLimit = 0x7fff;
+    static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
+    static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
+    static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
+    // packed true values of stored cells whose shift is `shift2`
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t shift2) const { return pk_sub_sat_i16(v, shift2); }
     uint32_t extMinusOpen2;
     __device__ __forceinline__ ArithI16Diag(int open, int ext) : extMinusOpen2(dup16(max(ext - open, -32768))) {}
     __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return pk_add_sat_i16(h, s); }
@@ -175,6 +192,56 @@ struct ArithI16Diag {
     __device__ __forceinline__ uint32_t fromInt(int v) const { return dup16(max(v, -32768)); }
     static __device__ __forceinline__ uint32_t lowest() { return 0x80008000u; }
     static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
+};
+
+// NW / HW / OV on anti-diagonally shifted values like ArithI16Diag, as unsigned patterns compared as
+// half floats (see "biased integer halves" further down; same idea in the general kernel, round 2).
+// Plain form of a value x of cell (i, j): P(x) = kU16Zero + x + (i + j) * ext. H[r] keeps the STORED
+// form S(h) = P(h) - c, c = open - ext >= 0, which is at once the value both gap kinds open with, so:
+//     d = S(Hd) + s''          s'' = s + 2 ext + c >= 0 (host: open + ext >= -min S): a plain integer add
+//     h = max3(d, E, F)         one v_pk_maximum3_f16
+//     hmo = h - c               integer subtract; also the next column's stored H
+//     E = max(E, hmo), F = max(F, hmo)
+// 2 integer adds + 3 half-float max + 1 v_perm per cell pair, against 2 saturating packed adds + 4
+// packed max + 1 v_perm. Padding (symbol and rows) scores c after the shift, so that chains of padding
+// cells never sink below lowest() + c and `h - c` can neither borrow from the other half nor leave the
+// normal half floats; it can therefore reach real
+// magnitudes, and the places that read answers mask rows and columns beyond the pair explicitly
+// (kWeakPad). The host checks the static range (every pattern within [0, 0x7BFF]); answers are turned
+// into packed true int16 values where they are read (toTrue).
+constexpr int kU16Zero = 0x1000;
+static_assert(kU16Zero == kUnsignedDiagZero, "common.h mirrors this");
+struct ArithU16Diag {
+    static constexpr bool kFloor = false;
+    static constexpr bool kDiag = true;
+    static constexpr int kLimit = 0x7fff;
+    static constexpr bool kStoresOpen = true;
+    static constexpr bool kWeakPad = true;
+    int c;
+    uint32_t c2, trueBias2;
+    __device__ __forceinline__ ArithU16Diag(int open, int ext)
+        : c(open - ext), c2((uint32_t)((open - ext) * 0x00010001)), trueBias2(dup16(kU16Zero - (open - ext))) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return h + s; }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max3_f16(d, e, f); }
+    __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
+        (void)held; (void)r;
+        best = pk_max3_f16(best, h, h);
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const { return pk_max_i16(a, b); }  // answers: true values
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return h; }   // stored form = opened plain form
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return h - c2; }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max3_f16(x, hmo, hmo); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return (uint32_t)((kU16Zero + v - c) * 0x00010001); }
+    // ("minus infinity" of the cells: the smallest NORMAL half-float pattern. Patterns below 0x0400 are
+    // denormals: they compare correctly, but a database with ragged groups - a third of its cells
+    // padding, all of them down there - ran 20 % slower with 0 here.)
+    static __device__ __forceinline__ uint32_t lowest() { return 0x04000400u; }
+    static __device__ __forceinline__ uint32_t answerLowest() { return 0x80008000u; }
+    static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(short)half; }
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t shift2) const {
+        const u16x2 r = __builtin_bit_cast(u16x2, v) - (__builtin_bit_cast(u16x2, shift2) + __builtin_bit_cast(u16x2, trueBias2));
+        return __builtin_bit_cast(uint32_t, r);
+    }
 };
 
 // 16-byte slots per profile row in LDS: odd, so that the 16 lanes of a
@@ -264,7 +331,7 @@ next_unit:
     };
     // shift a stored value of cell (i, j) back to its true value
     auto unshift = [&](uint32_t v, int i, int j) -> uint32_t {
-        if (Arith::kDiag) return pk_sub_sat_i16(v, dup16((i + j) * ext));
+        if (Arith::kDiag) return ar.toTrue(v, dup16((i + j) * ext));
         return v;
     };
 
@@ -277,7 +344,7 @@ next_unit:
     }
 
     uint32_t best = Arith::lowest(), held = Arith::lowest();  // maximum over all cells (TRACK_ALL)
-    uint32_t ans = Arith::lowest();                            // answer of the other regions
+    uint32_t ans = Arith::answerLowest();                      // answer of the other regions (true values)
     uint32_t H[R], E[R];
     // LOC state, one set per packed half (A = low, B = high): running best score with
     // its column / row, the same for the strip in flight (all-cells region), and the
@@ -423,7 +490,7 @@ next_unit:
                             const uint32_t hmo = ar.cellOpen(h);
                             E[r] = ar.gap(E[r], hmo);
                             f = ar.gap(f, hmo);
-                            H[r] = h;
+                            H[r] = Arith::kStoresOpen ? hmo : h;
                             dsum = dnext;
                         }
                         // pins the schedule: the block's cells are finished before the loads
@@ -495,7 +562,7 @@ next_unit:
                                         asm volatile("" : "+v"(off));
                                     }
                                     if (s * R + r < Q) {
-                                        const uint32_t hv = Arith::kDiag ? pk_sub_sat_i16(H[r], offR) : H[r];
+                                        const uint32_t hv = Arith::kDiag ? ar.toTrue(H[r], offR) : H[r];
                                         const int hA = Arith::toInt(hv & 0xffffu), hB = Arith::toInt(hv >> 16);
                                         if (hA >= mA) { mA = hA; ra = r; }
                                         if (hB >= mB) { mB = hB; rb = r; }
@@ -516,8 +583,15 @@ next_unit:
                             for (int r = 1; r < R; ++r)
                                 if (r == rl) hq = H[r];
                             hq = unshift(hq, Q - 1, j);
-                            if (region == kLastCell) ans = selectHalves(ans, hq, lastMask);
-                            else ans = ar.max2(ans, hq);  // last row; padded columns never exceed real ones
+                            if (region == kLastCell) {
+                                ans = selectHalves(ans, hq, lastMask);
+                            } else if (Arith::kWeakPad) {
+                                // last row, columns of the target only
+                                const uint32_t inside = ((j < lenA) ? 0x0000ffffu : 0u) | ((j < lenB) ? 0xffff0000u : 0u);
+                                ans = selectHalves(ans, ar.max2(ans, hq), inside);
+                            } else {
+                                ans = ar.max2(ans, hq);  // last row; padded columns never exceed real ones
+                            }
                         }
                         if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastMask != 0) != 0) {
                             // some lane is on its target's last column: maximum over this strip's rows
@@ -525,13 +599,14 @@ next_unit:
                             // here instead of R live offsets)
                             uint32_t off = Arith::kDiag ? dup16((s * R + j) * ext) : 0u;
                             const uint32_t step = Arith::kDiag ? dup16(ext) : 0u;
-                            uint32_t cm = Arith::kDiag ? pk_sub_sat_i16(H[0], off) : H[0];
+                            uint32_t cm = Arith::kDiag ? ar.toTrue(H[0], off) : H[0];
 #pragma unroll
                             for (int r = 1; r < R; ++r) {
                                 if (Arith::kDiag) {
                                     off += step;  // halves stay below 32000: no carry between them
                                     asm volatile("" : "+v"(off));
-                                    cm = ar.max2(cm, pk_sub_sat_i16(H[r], off));
+                                    // (rows beyond the query only matter when padding can score: kWeakPad)
+                                    if (!Arith::kWeakPad || s * R + r < Q) cm = ar.max2(cm, ar.toTrue(H[r], off));
                                 } else {
                                     cm = ar.max2(cm, H[r]);
                                 }
