@@ -239,9 +239,10 @@ hipError_t launchPack(const PackArgs& a, int64_t totalChunks, hipStream_t stream
 hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
                               const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
                               int nTargets, int64_t sliceStart, unsigned long long* keys, int32_t* overflowCount,
-                              hipStream_t stream);
+                              hipStream_t stream, int scoreBias = 0);
 hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
-                            hipStream_t stream);
+                            hipStream_t stream, int scoreBias = 0);
+hipError_t launchFillInt32(int32_t* out, int n, int32_t value, hipStream_t stream);
 // takeMax: several view positions (segments) may belong to one target; `out` starts at 0
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,

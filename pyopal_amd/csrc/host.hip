@@ -928,6 +928,24 @@ struct Search {
             const int64_t rounded = (reach + 127) / 128 * 128;
             if (rounded <= 2048 && db->maxLen > segmentStride((int)rounded) + rounded) overlap = (int)rounded;
         }
+        // HW (the whole query, free ends in the target) can be cut the same way. Its optimum is at least
+        // -(open + (Q - 1) ext) (the query gapped against nothing) and at most Q max(S) minus what its
+        // gap columns in the target cost, so it has at most (Q max(S) + open + (Q - 1) ext) / min(open, ext)
+        // of them and spans Q + that many columns; a window's penalised left border stands for real
+        // alignments (the query's head gapped from the free top border), so no window exceeds the whole
+        // target and the one that holds the optimal alignment reaches it. NW spans the whole target by
+        // definition; OV's last-column candidates only exist in a target's last window: both stay whole.
+        int keyBias = 0;
+        if (mode == OPAL_MODE_HW && std::min(open, ext) > 0 && Q < 4096 && db->maxLen < (1 << 24) &&
+            !getenv("MIOPAL_NO_SEGMENTS")) {
+            const int64_t gaps = ((int64_t)Q * std::max(maxScore, 0) + open + ((int64_t)Q - 1) * ext) / std::min(open, ext);
+            const int64_t rounded = (Q + gaps + 1 + 127) / 128 * 128;
+            const int64_t lowest = 2 * (int64_t)open + ((int64_t)Q + rounded + 8) * ext + (int64_t)Q * std::max(0, -minScore);
+            if (rounded <= 2048 && db->maxLen > segmentStride((int)rounded) + rounded && lowest < (1 << 21)) {
+                overlap = (int)rounded;
+                keyBias = 1 << 22;   // scores above -2^22 in the key's 24-bit score field
+            }
+        }
         std::shared_ptr<View> view;
         RC_TRY(getView(db, start, end, overlap, &view));
         spt.mark("    view lookup");
@@ -943,7 +961,9 @@ struct Search {
             RC_TRY(ws->get(kKeys, (size_t)n * sizeof(unsigned long long), &keys));
             HIP_TRY(hipMemsetAsync(keys, 0, (size_t)n * sizeof(unsigned long long), stream));
         } else if (overlap > 0) {
-            HIP_TRY(hipMemsetAsync(d_score, 0, (size_t)n * sizeof(int32_t), stream));
+            // (Smith-Waterman scores start from 0, HW scores from "minus infinity")
+            if (keyBias) HIP_TRY(launchFillInt32(d_score, (int)n, INT32_MIN, stream));
+            else HIP_TRY(hipMemsetAsync(d_score, 0, (size_t)n * sizeof(int32_t), stream));
         }
         // (a target whose windows are neighbours in the view is queued once)
         auto queueWhole = [&](std::vector<PairJob>& list, int32_t id) {
@@ -1286,8 +1306,8 @@ struct Search {
                     return fail(MIOPAL_ERR_INTERNAL, "segmented view with side jobs");
                 HIP_TRY(launchScatterKeyed(ia.score, ia.endI, ia.endJ, (const uint8_t*)vo, view->d_ids,
                                            view->d_segStart, nScatter, start, (unsigned long long*)keys,
-                                           mayOverflow ? (int32_t*)ct : nullptr, stream));
-                HIP_TRY(launchDecodeKeys((const unsigned long long*)keys, (int)n, d_score, d_endI, d_endJ, stream));
+                                           mayOverflow ? (int32_t*)ct : nullptr, stream, keyBias));
+                HIP_TRY(launchDecodeKeys((const unsigned long long*)keys, (int)n, d_score, d_endI, d_endJ, stream, keyBias));
             } else {
                 HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos,
                                       nScatter, start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0,

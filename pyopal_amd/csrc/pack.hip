@@ -100,14 +100,17 @@ __global__ void scatter_ends_kernel(const int32_t* viewEndI, const int32_t* view
 // the whole target). One 64-bit atomicMax per window on
 //     score << 40 | (2^24 - 1 - column) << 16 | (2^16 - 1 - row)
 // into zero-initialised keys, then a pass that unpacks them.
+// scoreBias = 0: Smith-Waterman (scores below 1 have no location and leave the key 0); scoreBias > 0:
+// HW, whose scores can be negative - every window with an end column takes part, the score field
+// holds score + scoreBias > 0.
 __global__ void scatter_keyed_kernel(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
                                      const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
                                      int nTargets, int64_t sliceStart, unsigned long long* keys,
-                                     int32_t* overflowCount) {
+                                     int32_t* overflowCount, int scoreBias) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nTargets) return;
     if (overflowCount != nullptr && viewOverflow[k]) atomicAdd(overflowCount, 1);
-    const int score = viewScore[k];
+    const int score = viewScore[k] + scoreBias;
     if (score <= 0 || viewEndJ[k] < 0) return;
     const unsigned long long col = (unsigned long long)(segStart[k] + viewEndJ[k]);
     const unsigned long long row = (unsigned long long)viewEndI[k];
@@ -117,30 +120,45 @@ __global__ void scatter_keyed_kernel(const int32_t* viewScore, const int32_t* vi
 }
 
 __global__ void decode_keys_kernel(const unsigned long long* keys, int n, int32_t* score, int32_t* endI,
-                                   int32_t* endJ) {
+                                   int32_t* endJ, int scoreBias) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const unsigned long long key = keys[k];
     const int s = (int)(key >> 40);
-    score[k] = s;
-    endI[k] = s > 0 ? (int)(0xFFFFull - (key & 0xFFFFull)) : -1;
-    endJ[k] = s > 0 ? (int)(0xFFFFFFull - ((key >> 16) & 0xFFFFFFull)) : -1;
+    // (an untouched key: no window reported anything - Smith-Waterman score 0; with a bias the target
+    // is one the int32 kernel computes afterwards, e.g. an empty one)
+    score[k] = key != 0 ? s - scoreBias : 0;
+    endI[k] = key != 0 ? (int)(0xFFFFull - (key & 0xFFFFull)) : -1;
+    endJ[k] = key != 0 ? (int)(0xFFFFFFull - ((key >> 16) & 0xFFFFFFull)) : -1;
+}
+
+__global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = value;
 }
 
 hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI, const int32_t* viewEndJ,
                               const uint8_t* viewOverflow, const int32_t* ids, const int32_t* segStart,
                               int nTargets, int64_t sliceStart, unsigned long long* keys, int32_t* overflowCount,
-                              hipStream_t stream) {
+                              hipStream_t stream, int scoreBias) {
     if (nTargets <= 0) return hipSuccess;
     hipLaunchKernelGGL(scatter_keyed_kernel, dim3((nTargets + 255) / 256), dim3(256), 0, stream, viewScore,
-                       viewEndI, viewEndJ, viewOverflow, ids, segStart, nTargets, sliceStart, keys, overflowCount);
+                       viewEndI, viewEndJ, viewOverflow, ids, segStart, nTargets, sliceStart, keys, overflowCount,
+                       scoreBias);
     return hipGetLastError();
 }
 
 hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
-                            hipStream_t stream) {
+                            hipStream_t stream, int scoreBias) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ);
+    hipLaunchKernelGGL(decode_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ,
+                       scoreBias);
+    return hipGetLastError();
+}
+
+hipError_t launchFillInt32(int32_t* out, int n, int32_t value, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_int32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, out, n, value);
     return hipGetLastError();
 }
 

@@ -422,6 +422,58 @@ def test_segmented_views_every_score(capi, qlen, gaps, matrix):
         db.close()
 
 
+@pytest.mark.parametrize("qlen,gaps,matrix", [(53, (3, 1), "B62"), (20, (3, 1), "B62"), (64, (11, 1), "B50"),
+                                                (53, (1, 2), "B62"), (30, (5, 2), "B62"), (53, (3, 0), "B62"),
+                                                (100, (11, 1), "B62")])
+def test_segmented_views_hw(capi, qlen, gaps, matrix):
+    """HW (whole query, free ends in the target) on long targets cut into overlapping windows: every
+    score against the AVX2 checker, end locations and alignments of the longest targets against the
+    scalar one. Scores are negative for most targets (the merge starts from minus infinity, the keys
+    carry a bias); hits are planted across window borders; ext = 0 rules windows out."""
+    rng = np.random.default_rng(11 * qlen + gaps[0])
+    lengths = np.clip(rng.lognormal(5.3, 0.6, size=20_000), 1, 2500).astype(np.int64)
+    lengths[rng.integers(0, len(lengths), size=300)] = rng.integers(2500, 8100, size=300)
+    lengths[rng.integers(0, len(lengths), size=4)] = [9000, 12_345, 8193, 20_000]
+    lengths[:3] = [0, 1, 2]
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, qlen)
+    order = np.argsort(lengths)
+    for k in order[-60:]:
+        copy = _data.mutate(rng, q, 0.1)
+        at = int(rng.integers(0, max(1, lengths[k] - len(copy))))
+        m = min(len(copy), int(lengths[k]) - at)
+        res[off[k] + at:off[k] + at + m] = copy[:m]
+    mat = B62 if matrix == "B62" else B50
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(q, mat, gaps[0], gaps[1], "score", "hw")["score"]
+        routed = capi.DeviceDatabase.last_routing()
+        cpu = _cpu_baseline.CpuDatabase(res, off)
+        want = cpu.search(q, mat, gaps[0], gaps[1], "hw", 8)
+        cpu.close()
+        np.testing.assert_array_equal(got, want)
+        if gaps[1] > 0 and gaps[0] > 0 and qlen <= 64:
+            assert routed[0] < 64, f"long targets should stay in the packed kernel, got {routed}"
+        part = db.search(q, mat, gaps[0], gaps[1], "score", "hw", 1000, 15_000)["score"]
+        np.testing.assert_array_equal(part, want[1000:15_000])
+        end = db.search(q, mat, gaps[0], gaps[1], "end", "hw")
+        np.testing.assert_array_equal(end["score"], want)
+        sample = np.unique(np.concatenate([order[-120:], rng.integers(0, len(lengths), size=200), [0, 1, 2]]))
+        sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+        mode = "full" if qlen == 53 else "end"
+        ref = _oracle.search(q, sres, soff, mat, gaps[0], gaps[1], mode, "hw")
+        for key in ("score", "end_q", "end_t"):
+            np.testing.assert_array_equal(end[key][sample], ref[key], err_msg=key)
+        if mode == "full":
+            full = db.search(q, mat, gaps[0], gaps[1], "full", "hw")
+            for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+                np.testing.assert_array_equal(full[key][sample], ref[key], err_msg=key)
+            for x, k in enumerate(sample):
+                assert full["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
+    finally:
+        db.close()
+
+
 @pytest.mark.parametrize("config", ["", "4,4", "4,2", "4,1", "8,8", "8,4", "3,1", "6,2", "5,1", "16,8"])
 def test_strip_configurations(capi, monkeypatch, config):
     """Queries of more than 64 rows: every split into strips and wavefronts that the dispatch
