@@ -264,3 +264,23 @@ def test_global_modes_no_target_leaves_the_lanes_for_its_length(capi, algo):
             assert got.min() < -20000
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("switch", [None, "MIOPAL_NO_BIASED", "MIOPAL_NO_PAIR_TABLE"])
+def test_scores_beyond_the_half_float_range(capi, monkeypatch, switch):
+    # match 1024: a copy of the 64-residue query scores 65536, beyond the largest finite half float
+    # (65504), where a half-float lane would turn inf and, next to -inf padding, NaN - which converts to
+    # 0 and would slip through the "best >= limit" flag. Every rung must hand such lanes on; the answer
+    # comes from the int32 kernel whatever the first rung was.
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    rng = np.random.default_rng(64)
+    m = scaled_identity(24, 1024, -1024)
+    query = _data.random_protein(rng, 64)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 200, size=300)]
+    for k in (64, 63, 48, 33, 32, 31, 26, 25, 24, 2):   # 65536 .. 2048: every rung's limit is crossed
+        seqs.append(np.concatenate([_data.random_protein(rng, 7), query[:k], _data.random_protein(rng, 4)]))
+    seqs.append(np.concatenate([query, query]))
+    res, off = _oracle.flatten(seqs)
+    for go, ge in ((2000, 1000), (30, 10)):
+        check(capi, query, res, off, m, go, ge, expect_kernel=None, tag=f"match 1024 gap {go}/{ge} {switch}")
