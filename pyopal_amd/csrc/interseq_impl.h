@@ -1266,14 +1266,13 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 //  * with a free top border (HW, OV) x is bounded and sigma is rebased like the Smith-Waterman
 //    kernel's; with a penalised one (NW) x + j ext is bounded and sigma just grows (as an int).
 // End locations (optional): the scan rules of oracle/opal_oracle.c on those per-column values.
-// Eight wavefronts per workgroup (two per SIMD, up to 256 VGPRs): beside H[R], E[R] this kernel keeps
-// per-lane answers, lengths and locations, and hipcc's schedule of the column needs more registers
-// than the Smith-Waterman one; two wavefronts per SIMD issue within a few per cent of three
-// (profiles/r02_ubench_mix.txt).
-constexpr int kGlobalWaves = 8;
+// Twelve wavefronts per workgroup (three per SIMD, 168 VGPRs) up to 54 rows, eight (256 VGPRs) beyond:
+// beside H[R], E[R] this kernel keeps per-lane answers, lengths and locations.
+__host__ __device__ constexpr int globalWaves(int rows) { return rows <= 54 ? 12 : 8; }
 
 template <int R>
-__global__ __launch_bounds__(kGlobalWaves * kLanes) void interseq_pair_global_kernel(InterseqArgs a) {
+__global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_kernel(InterseqArgs a) {
+    constexpr int kGlobalWaves = globalWaves(R);
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
     constexpr int NB4 = (R + 3) / 4;
     extern __shared__ uint4 pairs[];
@@ -1306,8 +1305,9 @@ __global__ __launch_bounds__(kGlobalWaves * kLanes) void interseq_pair_global_ke
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    constexpr int kTier[4][2] = {{0, 7}, {1, 6}, {2, 5}, {3, 4}};
-    const int tier = kTier[wave & 3][wave >> 2];
+    constexpr int kTier12[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
+    constexpr int kTier8[4][2] = {{0, 7}, {1, 6}, {2, 5}, {3, 4}};
+    const int tier = kGlobalWaves == 12 ? kTier12[wave & 3][wave >> 2] : kTier8[wave & 3][(wave >> 2) & 1];
     const int firstDynamic = kGlobalWaves * gridDim.x;
     const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
     bool firstRound = true;
@@ -1414,6 +1414,9 @@ __global__ __launch_bounds__(kGlobalWaves * kLanes) void interseq_pair_global_ke
                         const uint32_t h = pk_max3_f16(dsum, E[r], f);
                         const uint32_t hmo = h - openMinusExt2;
                         E[r] = pk_max3_f16(E[r], hmo, hmo);
+                        // (here, not whenever the scheduler likes: E is off the critical path, and the R
+                        // deferred updates would each hold on to their hmo)
+                        asm volatile("" : "+v"(E[r]));
                         if (r + 1 < R) f = pk_max3_f16(f, hmo, hmo) - ext2;
                         H[r] = h;
                         dsum = dnext;
@@ -1509,6 +1512,7 @@ static hipError_t launchPairGlobalR(const InterseqArgs& a, int computeUnits, hip
             return e;
         }
     }
+    constexpr int kGlobalWaves = globalWaves(R);
     const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kGlobalWaves - 1) / kGlobalWaves));
     hipLaunchKernelGGL((interseq_pair_global_kernel<R>), dim3(blocks), dim3(kGlobalWaves * kLanes), lds, stream, a);
     return hipGetLastError();
