@@ -198,8 +198,8 @@ def main():
                 "kernel_ms": round(k_ms, 4),
                 "kernel_gcups": round(float(Q) * N * L / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
                 "algorithmic_bytes": alg_bytes,
-                "note": "integer-VALU-bound by construction (3.3 VALU instructions per cell, "
-                        "0.02 B/cell): see DESIGN.md",
+                "note": "integer-VALU-bound by construction (6.9 VALU instructions per pair of cells of a "
+                        "lane, 0.02 B/cell): see DESIGN.md",
                 # secondary ceiling: VALU issue, from SQ_INSTS_VALU of this binary
                 "valu_issue": valu_ceiling(Q, k_ms, N, L, pmc),
             },
@@ -228,15 +228,15 @@ def valu_ceiling(Q, kernel_ms, N, L, pmc):
     simds, clock_hz = 1024, 2.4e9
     achieved = float(Q) * N * L / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     out = {"achieved": round(achieved, 1), "unit": "GCUPS", "instructions_per_launch": None,
-           "instructions_per_cell": None, "cycles_per_instruction": None, "full_rate_peak": None, "frac": None}
+           "instructions_per_cell_pair": None, "cycles_per_instruction": None, "full_rate_peak": None, "frac": None}
     if pmc and pmc.get("valu_instructions_per_launch") and kernel_ms > 0:
         instr = pmc["valu_instructions_per_launch"]   # wave64 instructions
         cells = float(Q) * N * L
-        per_cell = instr * 128.0 / cells              # one wavefront instruction covers 128 targets
+        per_pair = instr * 128.0 / cells              # per lane: one instruction updates one pair of cells
         full = simds * clock_hz / 2.0 / instr * cells / 1e9
         out.update({
             "instructions_per_launch": instr,
-            "instructions_per_cell": round(per_cell, 3),
+            "instructions_per_cell_pair": round(per_pair, 3),
             "cycles_per_instruction": round(kernel_ms * 1e-3 * clock_hz * simds / instr, 3),
             "full_rate_peak": round(full, 1),
             "frac": round(achieved / full, 3),

@@ -36,7 +36,7 @@ def test_bench_line_small_workload():
     assert "scores left in HBM" in line["config"]["workload"]
     assert cpu["value_one_thread"] > 0 and cpu["cpu_model"] and cpu["host_physical_cores"] >= cpu["cores"] >= 1
     assert roof["traffic"] is None    # 50k targets is not the profiled workload
-    assert set(roof["valu_issue"]) >= {"achieved", "full_rate_peak", "frac", "cycles_per_instruction"}
+    assert set(roof["valu_issue"]) >= {"achieved", "full_rate_peak", "frac", "cycles_per_instruction", "instructions_per_cell_pair"}
     strong = line["extras"]["cfg5_strong"]
     assert strong["scaling"] == "strong" and strong["gcups"] > 0 and sum(strong["targets_per_rank"]) == 250000
 
