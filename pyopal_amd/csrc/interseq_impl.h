@@ -220,7 +220,7 @@ struct ArithU16Diag {
     int c;
     uint32_t c2, trueBias2;
     __device__ __forceinline__ ArithU16Diag(int open, int ext)
-        : c(open - ext), c2((uint32_t)((open - ext) * 0x00010001)), trueBias2(dup16(kU16Zero - (open - ext))) {}
+        : c(open - ext), c2((uint32_t)(open - ext) * 0x00010001u), trueBias2(dup16(kU16Zero - (open - ext))) {}
     __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return h + s; }
     __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max3_f16(d, e, f); }
     __device__ __forceinline__ void track(uint32_t& best, uint32_t& held, uint32_t h, int r) const {
@@ -231,7 +231,7 @@ struct ArithU16Diag {
     __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return h; }   // stored form = opened plain form
     __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return h - c2; }
     __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max3_f16(x, hmo, hmo); }
-    __device__ __forceinline__ uint32_t fromInt(int v) const { return (uint32_t)((kU16Zero + v - c) * 0x00010001); }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return (uint32_t)(kU16Zero + v - c) * 0x00010001u; }
     // ("minus infinity" of the cells: the smallest NORMAL half-float pattern. Patterns below 0x0400 are
     // denormals: they compare correctly, but a database with ragged groups - a third of its cells
     // padding, all of them down there - ran 20 % slower with 0 here.)
@@ -998,7 +998,8 @@ static __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, r);
 }
 // the same signed value in both halves, as one integer (see above)
-static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)(v * 0x00010001); }
+// (unsigned arithmetic: the product wraps modulo 2^32 for negative or large v, no signed overflow)
+static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)v * 0x00010001u; }
 
 template <int R, bool LOC>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kernel(InterseqArgs a) {
