@@ -489,6 +489,9 @@ next_unit:
                             if (TRACK_ALL) ar.track(best, held, h, r);
                             const uint32_t hmo = ar.cellOpen(h);
                             E[r] = ar.gap(E[r], hmo);
+                            // (at its row: E is off the critical path, and hipcc defers the R updates to
+                            // the end of the block, each holding on to its hmo)
+                            asm volatile("" : "+v"(E[r]));
                             f = ar.gap(f, hmo);
                             H[r] = Arith::kStoresOpen ? hmo : h;
                             dsum = dnext;

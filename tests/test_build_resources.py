@@ -34,13 +34,10 @@ def test_hot_kernels_do_not_spill():
     hot = {n: k for n, k in ks.items() if "interseq" in n or "perpair" in n}
     assert len(hot) >= 40, sorted(hot)
     bad = {n: k for n, k in hot.items() if k.get("VGPRs Spill", 0) or k.get("ScratchSize [bytes/lane]", 0)}
-    # Known: the 8-wavefront, 64-row instantiations of the general kernel (512 threads: 256 VGPRs) park
-    # a few scalars in scratch outside the cell loop (<= 128 bytes per lane); nothing else may.
+    # No vector register may spill. Scalars (kernel arguments kept across the unit loop of the general
+    # kernel) parked through a VGPR show up as a few bytes of scratch without a vector spill: allowed.
     for name in list(bad):
-        if "interseq_kernelILi64E" in name and "ELi8E" in name and bad[name]["ScratchSize [bytes/lane]"] <= 128:
-            del bad[name]
-        # scalars (kernel arguments kept across the unit loop) parked through a VGPR: no vector spill
-        elif "interseq_kernel" in name and not bad[name].get("VGPRs Spill", 0) and bad[name]["ScratchSize [bytes/lane]"] <= 64:
+        if "interseq_kernel" in name and not bad[name].get("VGPRs Spill", 0) and bad[name]["ScratchSize [bytes/lane]"] <= 64:
             del bad[name]
     assert not bad, bad
 
