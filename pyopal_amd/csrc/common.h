@@ -45,6 +45,7 @@ struct InterseqArgs {
     int* unitCounter;          // zeroed before the launch: next (round, group) unit
     int* unitFlags;            // [nGroups], zeroed: rounds of the group that are complete
     uint2* unitPartial;        // [nGroups][W][64]: {all-cells best, region answer} carried between rounds
+    int scoreBias;             // ArithSwU16: K, added to every profile entry and taken off the stored H
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
@@ -160,8 +161,10 @@ enum InterseqFlavour : int {
     kSignedInt16 = 2,         // NW / HW / OV, signed saturating int16
     kSignedInt16AllCells = 3, // anchored reverse pass: signed, every cell is a candidate
     kSignedInt16Diag = 4,     // NW / HW / OV on anti-diagonally shifted values (6 ops per cell pair)
-    kUnsignedDiag = 5         // the same on unsigned patterns compared as half floats (5 cheaper ops, interseq_impl.h)
+    kUnsignedDiag = 5,        // the same on unsigned patterns compared as half floats (5 cheaper ops, interseq_impl.h)
+    kSwShifted = 6            // Smith-Waterman scores on column-shifted unsigned patterns (ArithSwU16)
 };
+constexpr int kSwShiftZero = 0x1000;       // = kSwU16Zero
 constexpr int kUnsignedDiagZero = 0x1000;  // = kU16Zero
 hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, InterseqFlavour flavour,
                           bool locate, hipStream_t stream);
@@ -209,6 +212,7 @@ hipError_t launchInterseqSignedLoc(const InterseqArgs& a, int rowsPerStrip, int 
 hipError_t launchInterseqSignedAll(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedDiag(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
+hipError_t launchInterseqSwShifted(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqUnsignedDiag(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqUnsignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);

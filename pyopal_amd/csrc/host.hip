@@ -1069,13 +1069,29 @@ struct Search {
             const bool usePair = sw && nStrips == 1 && !(noPair && noPair[0] == '1') &&
                                  interseqPairFits(biasedFits ? pairRows : rows, nSym) && (!locate || biasedFits);
             const bool biased = usePair && biasedFits;
+            // Smith-Waterman scores in the general kernel (several strips, or a pair table that does not
+            // fit LDS): column-shifted unsigned patterns (ArithSwU16) when the longest packed target
+            // leaves a range worth having - zero + ext x columns + score below 0x7C00.
+            int swBias = 0, swLimit = 0;
+            bool swShifted = false;
+            if (sw && !locate && !usePair && useHalf && !getenv("MIOPAL_NO_SW_SHIFT")) {
+                swBias = std::max(0, -(minScore + ext));                       // profile entries s + ext + K >= 0
+                const int64_t stepUp = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
+                const int64_t lim = 0x7C00 - kSwShiftZero - (int64_t)ext * (view->maxPackedLen + 8) -
+                                    std::max<int64_t>(0, stepUp - 0x0400);
+                if (lim >= 4096 && swBias + ext <= 0x0800 && open - ext <= 0x0800 && stepUp <= 0x1000 &&
+                    (int64_t)maxScore + ext + swBias < 0x4000) {
+                    swShifted = true;
+                    swLimit = (int)lim;
+                }
+            }
             // Half floats turn a sum above 65504 into +inf, and inf + (-inf padding) into NaN, which
             // the flag `best >= 2048` would miss (NaN converts to 0): only matrices whose best
             // possible score stays finite take the half-float rung.
-            const bool halfFloat = sw && useHalf && !biased && maxScore <= 1024 && minScore >= -1024 &&
+            const bool halfFloat = sw && useHalf && !biased && !swShifted && maxScore <= 1024 && minScore >= -1024 &&
                                    (int64_t)std::min<int64_t>(Q, db->maxLen) * std::max(maxScore, 0) < 60000;
-            InterseqFlavour flavour = sw ? (halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
-            int profileShift = 0;
+            InterseqFlavour flavour = sw ? (swShifted ? kSwShifted : halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
+            int profileShift = swShifted ? ext + swBias : 0;
             // One-strip NW / HW / OV: the pair-table kernel on biased integer halves (interseq_impl.h).
             // The true values around a pattern's zero are bounded by the query, not by the targets'
             // lengths, so no target is redone at 32 bit; the bounds are static:
@@ -1143,6 +1159,7 @@ struct Search {
             };
             // (the unsigned shifted flavour: padding scores open - ext after the shift, see ArithU16Diag)
             const int16_t padValue = (biased || globalPair) ? (int16_t)kBiasedPad
+                                     : swShifted ? (int16_t)0   // s + ext + K = 0: a true score of -(ext + K) <= 0
                                      : flavour == kUnsignedDiag ? (int16_t)(open - ext)
                                      : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
             std::vector<int16_t> prof((size_t)nSym * qPad, padValue);
@@ -1180,7 +1197,7 @@ struct Search {
                 queryBest += rowMax;
             }
             const int64_t reach = std::min<int64_t>((int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0), queryBest);
-            const int64_t limit = biased ? biasedLimit : halfFloat ? 2048 : 32767;
+            const int64_t limit = biased ? biasedLimit : swShifted ? swLimit : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
@@ -1209,7 +1226,8 @@ struct Search {
                 ia.endJ = (int32_t*)vj;
             }
             ia.overflow = sw ? (uint8_t*)vo : nullptr;
-            ia.biasedLimit = biasedLimit;
+            ia.biasedLimit = swShifted ? swLimit : biasedLimit;
+            ia.scoreBias = swBias;
             ia.biasedZero = (int)globalZero;
             ia.boundaryOff = view->d_boundaryOff;
             ia.priorityChunks = getenv("MIOPAL_NO_PRIORITY") ? INT32_MAX : (int)std::min<int64_t>(std::max<int64_t>(balancedChunks, 16), INT32_MAX);
@@ -1247,7 +1265,7 @@ struct Search {
                 HIP_TRY(hipEventCreate(&e1));
                 HIP_TRY(hipEventRecord(e0, stream));
             }
-            g_lastRouting[1] = 1;  // general kernel
+            g_lastRouting[1] = 1 + 32 * (int)flavour;  // general kernel and its lane arithmetic
             if (usePair || globalPair) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
@@ -1326,7 +1344,7 @@ struct Search {
                 int32_t count = 0;
                 RC_TRY(ws->stageDownload(&count, ct, sizeof(int32_t)));
                 RC_TRY(ws->finishDownloads());
-                if ((halfFloat || biased) && count > kMaxDirectRecompute) {
+                if ((halfFloat || biased || swShifted) && count > kMaxDirectRecompute) {
                     // many targets left the half-float range: second rung, int16 lanes,
                     // over the whole view (its results overwrite the first pass)
                     return scorePassImpl(d_score, d_endI, d_endJ, false);

@@ -14,6 +14,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
             case kSignedInt16AllCells: return launchInterseqSignedAllLoc(a, rowsPerStrip, waves, stream);
             case kSignedInt16Diag: return launchInterseqSignedDiagLoc(a, rowsPerStrip, waves, stream);
             case kUnsignedDiag: return launchInterseqUnsignedDiagLoc(a, rowsPerStrip, waves, stream);
+            case kSwShifted: return hipErrorInvalidValue;  // scores only
         }
         return hipErrorInvalidValue;
     }
@@ -24,6 +25,7 @@ hipError_t launchInterseq(const InterseqArgs& a, int rowsPerStrip, int waves, In
         case kSignedInt16AllCells: return launchInterseqSignedAll(a, rowsPerStrip, waves, stream);
         case kSignedInt16Diag: return launchInterseqSignedDiag(a, rowsPerStrip, waves, stream);
         case kUnsignedDiag: return launchInterseqUnsignedDiag(a, rowsPerStrip, waves, stream);
+        case kSwShifted: return launchInterseqSwShifted(a, rowsPerStrip, waves, stream);
     }
     return hipErrorInvalidValue;
 }

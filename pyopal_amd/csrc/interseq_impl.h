@@ -85,6 +85,7 @@ struct ArithSwI16 {
     static constexpr bool kFloor = true;    // Smith-Waterman
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // a best at or above this may have clipped
+    static constexpr bool kColShift = false;    // values of column j carry j * ext (ArithSwU16)
     static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
     static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
     static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
@@ -110,6 +111,7 @@ struct ArithSwF16 {
     static constexpr bool kFloor = true;
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 2048;
+    static constexpr bool kColShift = false;    // values of column j carry j * ext (ArithSwU16)
     static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
     static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
     static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
@@ -142,6 +144,7 @@ struct ArithI16 {
     static constexpr bool kFloor = false;   // NW / HW / OV / anchored reverse pass
     static constexpr bool kDiag = false;
     static constexpr int kLimit = 0x7fff;   // ranges are checked statically by the host
+    static constexpr bool kColShift = false;    // values of column j carry j * ext (ArithSwU16)
     static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
     static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
     static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
@@ -172,6 +175,7 @@ struct ArithI16Diag {
     static constexpr bool kFloor = false;
     static constexpr bool kDiag = true;
     static constexpr int kLimit = 0x7fff;
+    static constexpr bool kColShift = false;    // values of column j carry j * ext (ArithSwU16)
     static constexpr bool kStoresOpen = false;  // H[r] keeps h (true: h - (open - ext), ArithU16Diag)
     static constexpr bool kWeakPad = false;     // padding scores cannot win a max on their own
     static __device__ __forceinline__ uint32_t answerLowest() { return lowest(); }
@@ -215,6 +219,7 @@ struct ArithU16Diag {
     static constexpr bool kFloor = false;
     static constexpr bool kDiag = true;
     static constexpr int kLimit = 0x7fff;
+    static constexpr bool kColShift = false;    // values of column j carry j * ext (ArithSwU16)
     static constexpr bool kStoresOpen = true;
     static constexpr bool kWeakPad = true;
     int c;
@@ -244,6 +249,56 @@ struct ArithU16Diag {
     }
 };
 
+// Smith-Waterman in the general kernel on the representation of the pair-table kernel ("biased
+// integer halves" further down), round 2: unsigned patterns compared as half floats, values of
+// column j shifted by j * ext. Plain form of a value x of column j: P(x) = kSwU16Zero + x + j ext;
+// H[r] keeps the stored form S(h) = P(h) - K with K >= 0 chosen by the host so that the profile
+// entries s'' = s + ext + K are not negative (v_perm builds the pair of scores from 16-bit halves:
+// a plain integer add over both halves needs them non-negative):
+//     d = S(Hd) + s''                     plain form, on this column's scale
+//     h = max3(d, E, F)
+//     S(h) = h - K;  hmo = h - (open - ext)
+//     E = max3(E, hmo, zero');  F = max3(F, hmo, zero') - ext        zero' = the next column's zero
+// 4 integer adds + 3.5 max3 + 1 v_perm against 4 v_pk_add_f16 + 3.5 max3 + 1 v_perm, and an exact
+// range of a.biasedLimit (tens of thousands minus ext x the longest packed target) instead of 2048:
+// a 300-residue query's strong hits no longer send the whole view to the int16 rung. The all-cells
+// maximum is folded per column and unshifted there (an integer max of true values, sticky for the
+// inf / NaN patterns of a lane that left the range). No rebasing: the host only picks this flavour
+// when zero + ext x (longest packed target) leaves a range worth having. Scores only (the end-location
+// form keeps ArithSwF16: its row scans compare packed values of different columns).
+constexpr int kSwU16Zero = 0x1000;
+static_assert(kSwU16Zero == kSwShiftZero, "common.h mirrors this");
+struct ArithSwU16 {
+    static constexpr bool kFloor = true;
+    static constexpr bool kDiag = false;
+    static constexpr int kLimit = 0x7fff;       // (unused: the limit of this flavour is a.biasedLimit)
+    static constexpr bool kColShift = true;
+    static constexpr bool kStoresOpen = false;
+    static constexpr bool kWeakPad = false;
+    uint32_t c2, k2, ext2;
+    __device__ __forceinline__ ArithSwU16(int open, int ext, int K = 0)
+        : c2((uint32_t)(open - ext) * 0x00010001u), k2((uint32_t)K * 0x00010001u), ext2((uint32_t)ext * 0x00010001u) {}
+    __device__ __forceinline__ uint32_t addScore(uint32_t h, uint32_t s) const { return h + s; }
+    __device__ __forceinline__ uint32_t hmax(uint32_t d, uint32_t e, uint32_t f) const { return pk_max3_f16(d, e, f); }
+    __device__ __forceinline__ void track(uint32_t& cm, uint32_t& held, uint32_t h, int r) const {
+        if (r & 1) cm = pk_max3_f16(cm, held, h);
+        else held = h;
+    }
+    __device__ __forceinline__ uint32_t max2(uint32_t a, uint32_t b) const {   // answers: true values
+        const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+        return __builtin_bit_cast(uint32_t, r);
+    }
+    __device__ __forceinline__ uint32_t afterOpen(uint32_t h) const { return h; }   // (borders are set up by hand)
+    __device__ __forceinline__ uint32_t cellOpen(uint32_t h) const { return h - c2; }
+    __device__ __forceinline__ uint32_t gap(uint32_t x, uint32_t hmo) const { return pk_max3_f16(x, hmo, hmo); }
+    __device__ __forceinline__ uint32_t stored(uint32_t h) const { return h - k2; }
+    __device__ __forceinline__ uint32_t fromInt(int v) const { return (uint32_t)v * 0x00010001u; }
+    static __device__ __forceinline__ uint32_t lowest() { return 0u; }             // of the answers: true values
+    static __device__ __forceinline__ uint32_t answerLowest() { return 0u; }
+    static __device__ __forceinline__ int toInt(uint32_t half) { return (int)(half & 0xffffu); }
+    __device__ __forceinline__ uint32_t toTrue(uint32_t v, uint32_t) const { return v; }
+};
+
 // 16-byte slots per profile row in LDS: odd, so that the 16 lanes of a
 // ds_read_b128 lane group that hold different symbols land on different slots.
 template <int R>
@@ -254,6 +309,12 @@ struct ProfileLayout {
 // take the halves of `v` named by the 0 / 0xffff masks in `m`, keep `dst` elsewhere
 static __device__ __forceinline__ uint32_t selectHalves(uint32_t dst, uint32_t v, uint32_t m) {
     return (dst & ~m) | (v & m);
+}
+
+template <typename Arith>
+static __device__ __forceinline__ Arith makeArith(const InterseqArgs& a) {
+    if constexpr (Arith::kColShift) return Arith(a.gapOpen, a.gapExt, a.scoreBias);
+    else return Arith(a.gapOpen, a.gapExt);
 }
 
 // MULTI = false: the query fits one strip (no boundary traffic, no rounds).
@@ -316,7 +377,7 @@ next_unit:
     const int nChunks = a.groupChunks[g];
     if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);  // long group: critical path
     else if (unitMode) __builtin_amdgcn_s_setprio(0);
-    const Arith ar(a.gapOpen, a.gapExt);
+    const Arith ar = makeArith<Arith>(a);
     const uint4* gprof = reinterpret_cast<const uint4*>(a.profile);
     const int rowSlotsGlobal = a.qPad / 8;
     const int Q = a.qLen;
@@ -380,6 +441,8 @@ next_unit:
         }
 
         uint32_t hdiagTop = Arith::lowest();
+        // column-shifted flavour: the zero of the last column done (column -1 at a round's start)
+        uint32_t fl = 0u;
         if (active) {
             // stage this strip's slice of the query profile into the wavefront's LDS region
             for (int idx = lane; idx < a.nSymbols * (R / 8); idx += kLanes) {
@@ -390,6 +453,17 @@ next_unit:
             __builtin_amdgcn_wave_barrier();
             // column -1: left border H[i][-1] and the E it induces in column 0
             const int i0 = s * R;
+            if constexpr (Arith::kColShift) {
+                // H[r][-1] = 0 on column -1's scale (stored form), E[r][0] = 0 on column 0's
+                fl = ar.fromInt(kSwU16Zero) - ar.ext2;
+                const uint32_t h0 = ar.stored(fl), e0 = fl + ar.ext2;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    H[r] = h0;
+                    E[r] = e0;
+                }
+                hdiagTop = h0;
+            } else {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 uint32_t hl;
@@ -402,6 +476,7 @@ next_unit:
             // H[i0-1][-1]: diagonal of the strip's first row in column 0
             if (Arith::kFloor) hdiagTop = 0u;
             else hdiagTop = s == 0 ? ar.fromInt(Arith::kDiag ? -2 * ext : 0) : ar.fromInt(border(leftGap, i0 - 1));
+            }
         }
 
         uint2 cur = {0, 0}, nxt = {0, 0};
@@ -449,10 +524,19 @@ next_unit:
                     // row above the strip: H[i0-1][j-1] (diagonal) and the F entering row i0
                     uint32_t diag = hdiagTop;
                     uint32_t f;
+                    uint32_t fl1 = 0u, cm = 0u, cheld = 0u;   // column-shifted flavour only
+                    if constexpr (Arith::kColShift) {
+                        fl += ar.ext2;                    // this column's zero
+                        fl1 = fl + ar.ext2;               // the next column's
+                        asm volatile("" : "+v"(fl1));     // (a VGPR: max3 with a scalar operand issues slower)
+                        cm = cheld = fl;
+                    }
                     if (!MULTI || s == 0) {
-                        const uint32_t topH = Arith::kFloor ? 0u : ar.fromInt(border(topGap, j));  // H[-1][j]
+                        uint32_t topH = Arith::kFloor ? 0u : ar.fromInt(border(topGap, j));  // H[-1][j]
+                        if constexpr (Arith::kColShift) topH = ar.stored(fl);                 // 0 on this column's scale
                         hdiagTop = topH;
                         f = ar.afterOpen(topH);
+                        if constexpr (Arith::kColShift) f = fl;                               // F entering row 0: the floor
                     } else {
                         hdiagTop = b0.x;
                         f = b0.y;
@@ -486,19 +570,32 @@ next_unit:
                             uint32_t dnext = 0;
                             if (r + 1 < R) dnext = ar.addScore(H[r], score(r + 1));
                             const uint32_t h = ar.hmax(dsum, E[r], f);
-                            if (TRACK_ALL) ar.track(best, held, h, r);
                             const uint32_t hmo = ar.cellOpen(h);
+                            if constexpr (Arith::kColShift) {
+                                ar.track(cm, cheld, h, r);                     // this column's maximum
+                                E[r] = pk_max3_f16(E[r], hmo, fl1);
+                                asm volatile("" : "+v"(E[r]));
+                                f = pk_max3_f16(f, hmo, fl1) - ar.ext2;
+                                H[r] = ar.stored(h);
+                            } else {
+                            if (TRACK_ALL) ar.track(best, held, h, r);
                             E[r] = ar.gap(E[r], hmo);
                             // (at its row: E is off the critical path, and hipcc defers the R updates to
                             // the end of the block, each holding on to its hmo)
                             asm volatile("" : "+v"(E[r]));
                             f = ar.gap(f, hmo);
                             H[r] = Arith::kStoresOpen ? hmo : h;
+                            }
                             dsum = dnext;
                         }
                         // pins the schedule: the block's cells are finished before the loads
                         // (and v_perm) of the block after next may start
                         asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                    }
+                    if constexpr (Arith::kColShift) {
+                        // true values of this column's maximum: an integer max (sticky for inf / NaN patterns)
+                        if (R & 1) cm = pk_max3_f16(cm, cheld, cheld);
+                        best = ar.max2(best, cm - fl);
                     }
                     if (outGlobal) bout[((size_t)c * 4 + cc) * kLanes + lane] = make_uint2(H[R - 1], f);
                     if (W > 1 && outLds) ldsBnd[wave][c & 1][cc * kLanes + lane] = make_uint2(H[R - 1], f);
@@ -719,8 +816,9 @@ next_unit:
             a.score[base + lane] = lo;
             a.score[base + kLanes + lane] = hi;
             if (a.overflow) {
-                a.overflow[base + lane] = lo >= Arith::kLimit;
-                a.overflow[base + kLanes + lane] = hi >= Arith::kLimit;
+                const int limit = Arith::kColShift ? a.biasedLimit : Arith::kLimit;
+                a.overflow[base + lane] = lo >= limit;
+                a.overflow[base + kLanes + lane] = hi >= limit;
             }
         }
     }

@@ -27,7 +27,7 @@ def check(capi, query, res, off, matrix, go, ge, modes=("score", "end"), expect_
     try:
         for mode in modes:
             got = db.search(query, matrix, go, ge, mode, "sw")
-            kernel = capi.DeviceDatabase.last_routing()[1]
+            kernel = capi.DeviceDatabase.last_routing()[1] & 31
             want = _oracle.search(query, res, off, matrix, go, ge, mode, "sw")
             for key in want:
                 if key == "aln":
@@ -172,7 +172,7 @@ def test_steps_up_beyond_the_guard_band_take_another_flavour(capi):
     try:
         for mode in ("score", "end"):
             got = db.search(query, m, 1200, 100, mode, "sw")
-            assert capi.DeviceDatabase.last_routing()[1] != PAIR_BIASED
+            assert (capi.DeviceDatabase.last_routing()[1] & 15) != PAIR_BIASED
             want = _oracle.search(query, res, off, m, 1200, 100, mode, "sw")
             for key in want:
                 np.testing.assert_array_equal(got[key], want[key], err_msg=f"{mode} {key}")
@@ -203,7 +203,7 @@ def check_algo(capi, algo, query, res, off, matrix, go, ge, modes=("score", "end
     try:
         for mode in modes:
             got = db.search(query, matrix, go, ge, mode, algo)
-            kernel = capi.DeviceDatabase.last_routing()[1]
+            kernel = capi.DeviceDatabase.last_routing()[1] & 31
             want = _oracle.search(query, res, off, matrix, go, ge, mode, algo)
             for key in want:
                 if key == "aln":
@@ -284,3 +284,116 @@ def test_scores_beyond_the_half_float_range(capi, monkeypatch, switch):
     res, off = _oracle.flatten(seqs)
     for go, ge in ((2000, 1000), (30, 10)):
         check(capi, query, res, off, m, go, ge, expect_kernel=None, tag=f"match 1024 gap {go}/{ge} {switch}")
+
+
+# --- Smith-Waterman scores of several strips: column-shifted unsigned lanes of the general kernel ---
+GENERAL_SHIFTED = 1 + 32 * 6   # miopalLastRouting counts[1]: general kernel, kSwShifted
+GENERAL_HALF = 1 + 32 * 0
+GENERAL_INT16 = 1 + 32 * 1
+
+
+def shifted_check(capi, query, res, off, matrix, go, ge, expect=GENERAL_SHIFTED, tag=""):
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(query, matrix, go, ge, "score", "sw")["score"]
+        routed = capi.DeviceDatabase.last_routing()
+    finally:
+        db.close()
+    want = _oracle.search(query, res, off, matrix, go, ge, "score", "sw")["score"]
+    np.testing.assert_array_equal(got, want, err_msg=tag)
+    if expect is not None:
+        assert routed[1] == expect, f"{tag}: lane-per-target pass ran {routed[1]}"
+    return routed
+
+
+@pytest.mark.parametrize("qlen", [61, 64, 65, 100, 127, 128, 129, 192, 193, 333, 700])
+def test_shifted_lanes_every_kind_of_strip_count(capi, qlen):
+    rng = np.random.default_rng(4000 + qlen)
+    query = _data.random_protein(rng, qlen)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]
+    seqs += [np.concatenate([_data.random_protein(rng, int(rng.integers(0, 40))), _data.mutate(rng, query, 0.15),
+                             _data.random_protein(rng, int(rng.integers(0, 40)))]) for _ in range(20)]
+    seqs += [query[: qlen // 2], query[qlen // 3:], np.zeros(0, dtype=np.uint8)]
+    res, off = _oracle.flatten(seqs)
+    shifted_check(capi, query, res, off, B62, 11, 1, tag=f"Q={qlen}")
+
+
+@pytest.mark.parametrize("go,ge", [(3, 1), (1, 1), (2, 5), (0, 3), (5, 0), (0, 0), (14, 12), (40, 12), (700, 30)])
+def test_shifted_lanes_gap_models(capi, go, ge):
+    rng = np.random.default_rng(go * 100 + ge + 7)
+    query = _data.random_protein(rng, 150)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=300)]
+    seqs += [_data.mutate(rng, query, 0.2) for _ in range(30)]
+    res, off = _oracle.flatten(seqs)
+    # (whatever rung the gap model gets, the scores are the checker's)
+    shifted_check(capi, query, res, off, B62, go, ge, expect=None, tag=f"gap {go}/{ge}")
+
+
+def test_shifted_lanes_leave_their_range_and_are_redone(capi):
+    # match 100, ext 2, targets of at most ~420 residues: exact below 0x7C00 - 0x1000 - 2 (420 + 8) or so;
+    # copies of k query residues score 100 k on both sides of that (k = 267)
+    rng = np.random.default_rng(31)
+    m = scaled_identity(24, 100, -40)
+    query = _data.random_protein(rng, 300)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 400, size=300)]
+    ks = (300, 280, 270, 268, 267, 266, 265, 264, 263, 262, 260, 250, 100, 3)
+    for k in ks:
+        seqs.append(np.concatenate([_data.random_protein(rng, 30), query[:k], _data.random_protein(rng, 20)]))
+        seqs.append(np.concatenate([query[300 - k:], _data.random_protein(rng, 50)]))
+    res, off = _oracle.flatten(seqs)
+    routed = shifted_check(capi, query, res, off, m, 5, 2, tag="match 100")
+    limit = 0x7C00 - 0x1000 - 2 * (max(len(s) for s in seqs) + 64)
+    assert 2 * sum(1 for k in ks if 100 * k >= limit) <= routed[3] <= 2 * sum(1 for k in ks if 100 * k >= limit - 2000)
+
+
+def test_shifted_lanes_large_steps_lower_the_limit(capi):
+    # match + ext = 3000: a finite pattern could step over 0x7C00..0x7FFF; the limit gives the excess away
+    rng = np.random.default_rng(32)
+    m = scaled_identity(24, 2900, -900)
+    query = _data.random_protein(rng, 130)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 200, size=300)]
+    seqs += [np.concatenate([_data.random_protein(rng, 7), query[:k], _data.random_protein(rng, 3)])
+             for k in (130, 40, 12, 11, 10, 9, 8, 7, 6, 5, 4)]
+    res, off = _oracle.flatten(seqs)
+    shifted_check(capi, query, res, off, m, 1000, 100, tag="match 2900")
+
+
+def test_shifted_lanes_negative_scores_are_biased(capi):
+    # mismatch -900 at ext 1: profile entries are s + ext + 899 >= 0, the column term takes the 899 back
+    rng = np.random.default_rng(33)
+    m = scaled_identity(24, 60, -900)
+    query = _data.random_protein(rng, 200)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 300, size=300)]
+    seqs += [_data.mutate(rng, query, f) for f in (0.0, 0.01, 0.02, 0.05, 0.1)]
+    res, off = _oracle.flatten(seqs)
+    shifted_check(capi, query, res, off, m, 20, 1, tag="mismatch -900")
+    # beyond the room below zero: another rung, same scores
+    m = scaled_identity(24, 60, -3000)
+    routed = shifted_check(capi, query, res, off, m, 20, 1, expect=None, tag="mismatch -3000")
+    assert routed[1] in (GENERAL_HALF, GENERAL_INT16)
+
+
+def test_shifted_lanes_are_not_used_when_the_columns_eat_the_range(capi):
+    # ext 200 x a few hundred columns leaves nothing above zero: the half-float / int16 rungs run
+    rng = np.random.default_rng(34)
+    query = _data.random_protein(rng, 100)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(300, 400, size=330)]
+    seqs[3] = np.concatenate([seqs[3][:200], _data.mutate(rng, query, 0.05), seqs[3][200:250]])
+    res, off = _oracle.flatten(seqs)
+    routed = shifted_check(capi, query, res, off, B62, 210, 200, expect=None, tag="ext 200")
+    assert routed[1] in (GENERAL_HALF, GENERAL_INT16)
+    # at ext 1 the same targets fit, and so do much longer ones (Smith-Waterman searches see long
+    # targets through windows of a few query lengths)
+    shifted_check(capi, query, res, off, B62, 11, 1, tag="ext 1")
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1500, 2000, size=130)]
+    seqs[3] = np.concatenate([seqs[3][:900], _data.mutate(rng, query, 0.05), seqs[3][900:1000]])
+    res, off = _oracle.flatten(seqs)
+    shifted_check(capi, query, res, off, B62, 14, 12, tag="ext 12, long targets")
+
+
+def test_switch_restores_the_half_float_rung_of_the_general_kernel(capi, monkeypatch):
+    rng = np.random.default_rng(35)
+    query = _data.random_protein(rng, 150)
+    res, off = _data.random_db(rng, rng.integers(20, 300, size=500))
+    monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
+    shifted_check(capi, query, res, off, B62, 3, 1, expect=GENERAL_HALF, tag="switch")

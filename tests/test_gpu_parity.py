@@ -198,10 +198,14 @@ def test_sw_int16_saturation(capi):
     compare(gpu, ref, "score", "saturation")
 
 
-def test_sw_lane_width_ladder(capi):
+@pytest.mark.parametrize("first_rung", ["shifted", "half"])
+def test_sw_lane_width_ladder(capi, monkeypatch, first_rung):
     # half-float lanes are exact below 2048, int16 lanes below 32767, then int32:
     # thousands of close homologues push most targets past the first rung (so the
-    # whole view is redone with int16 lanes), a few past the second
+    # whole view is redone with int16 lanes), a few past the second. The column-shifted first rung
+    # (round 2) holds the 480-residue query's hits itself and only hands the 6500-residue ones on.
+    if first_rung == "half":
+        monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
     rng = np.random.default_rng(14)
     q = _data.random_protein(rng, 6500)
     short = q[:480].copy()
@@ -511,9 +515,13 @@ def test_unit_mode_of_multi_round_score_searches(capi, monkeypatch, config):
             compare(gpu, ref, "score", f"units {config} {algo} Q={qlen}")
 
 
-def test_segmented_view_with_lanes_leaving_the_half_float_range(capi):
-    """A window whose lane saturates the first rung (scores >= 2048) is flagged like any other
-    lane, and its target recomputed whole by the next rungs - over the merged window maxima."""
+@pytest.mark.parametrize("first_rung", ["shifted", "half"])
+def test_segmented_view_with_lanes_leaving_the_half_float_range(capi, monkeypatch, first_rung):
+    """A window whose lane saturates the half-float rung (scores >= 2048) is flagged like any other
+    lane, and its target recomputed whole by the next rungs - over the merged window maxima. The
+    column-shifted first rung of round 2 (ArithSwU16) holds these scores itself: nothing is redone."""
+    if first_rung == "half":
+        monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
     rng = np.random.default_rng(5)
     lengths = np.clip(rng.lognormal(5.3, 0.5, size=20_000), 10, 1500).astype(np.int64)
     lengths[:30] = rng.integers(4000, 7000, size=30)
@@ -530,7 +538,7 @@ def test_segmented_view_with_lanes_leaving_the_half_float_range(capi):
         cpu = _cpu_baseline.CpuDatabase(res, off)
         want = cpu.search_sw(q, B62, 5, 2, 8)
         cpu.close()
-        assert want.max() >= 2048 and routed[3] >= 1, (int(want.max()), routed)
+        assert want.max() >= 2048 and (routed[3] >= 1) == (first_rung == "half"), (int(want.max()), routed)
         np.testing.assert_array_equal(got, want)
         end = db.search(q, B62, 5, 2, "end", "sw")
         np.testing.assert_array_equal(end["score"], want)
