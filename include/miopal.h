@@ -59,6 +59,13 @@ int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int6
 
 void miopalDbDestroy(MiopalDb* db);
 
+/* opalSearchDatabase (include/opal.h) receives the whole database on every call; the library keeps
+ * the handles such calls built (device memory, pinned bounce buffers, streams: at most 4 handles of at
+ * most MIOPAL_SPARE_HANDLE_MB, default 4096, MiB of device memory each) and refills them on the next
+ * call. This releases everything kept that way. No reference counterpart.
+ */
+void miopalReleaseCaches(void);
+
 int64_t miopalDbCount(const MiopalDb* db);
 int64_t miopalDbTotalLength(const MiopalDb* db);
 /* Bytes of HBM held by the mirror (linear copy + packed views). */

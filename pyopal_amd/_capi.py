@@ -47,7 +47,7 @@ EXPORTS = [
     "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
-    "miopalLastRouting", "miopalSearchResults",
+    "miopalLastRouting", "miopalSearchResults", "miopalReleaseCaches",
 ]
 
 
@@ -111,6 +111,8 @@ def lib() -> ctypes.CDLL:
                                                c_i64, c_i64, c_vp, c_vp]
         L.miopalSetProfiling.restype = None
         L.miopalSetProfiling.argtypes = [c_vp, c_int]
+        L.miopalReleaseCaches.restype = None
+        L.miopalReleaseCaches.argtypes = []
         L.miopalLastRouting.restype = None
         L.miopalLastRouting.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.miopalLastKernelTime.restype = c_int

@@ -8,6 +8,7 @@
 // a device-resident database.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -338,6 +339,7 @@ struct View {
     int64_t* d_boundaryOff = nullptr;
     size_t deviceBytes = 0;
     void* d_meta = nullptr;          // one allocation behind d_ids .. d_boundaryOff (and the pack kernel's prefix)
+    size_t packCap = 0, metaCap = 0; // sizes of the two allocations (a refilled handle re-uses them)
     ~View() {
         if (d_pack) (void)hipFree(d_pack);
         if (d_meta) (void)hipFree(d_meta);
@@ -356,6 +358,9 @@ struct MiopalDb {
     std::vector<int64_t> offsets;  // host copy, [count + 1]
     uint8_t* d_residues = nullptr;
     int64_t* d_offsets = nullptr;
+    size_t residueCap = 0, offsetsCap = 0;   // allocated bytes (a handle may be refilled: opalSearchDatabase)
+    // device blocks of dropped views, kept for the views of the next filling (at most kSpareBlocks)
+    std::vector<std::pair<void*, size_t>> spareBlocks;
 
     struct ViewSlot {
         int64_t start, end;
@@ -396,6 +401,7 @@ struct MiopalDb {
         uploadFree.clear();
         ownedFree.clear();
         external.clear();
+        for (auto& b : spareBlocks) (void)hipFree(b.first);
         if (d_residues) (void)hipFree(d_residues);
         if (d_offsets) (void)hipFree(d_offsets);
     }
@@ -457,48 +463,245 @@ struct WorkspaceLease {
     }
 };
 
-// One-off host -> device copy (database and view construction) through a pinned bounce buffer,
-// so that the runtime never pins (and keeps a mapping of) the caller's or the C library's
-// pageable memory: see Workspace::finishDownloads.
-int uploadOnce(void* deviceDst, const void* src, size_t bytes) {
-    if (bytes == 0) return 0;
-    const size_t piece = std::min<size_t>(bytes, 32u << 20);
-    void* bounce[2] = {nullptr, nullptr};
-    hipStream_t s = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        if (s) (void)hipStreamDestroy(s);
-        for (void* b : bounce)
-            if (b) (void)hipHostFree(b);
-    };
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc(&bounce[0], piece, hipHostMallocDefault) != hipSuccess ||
-        (bytes > piece && hipHostMalloc(&bounce[1], piece, hipHostMallocDefault) != hipSuccess)) {
-        cleanup();
-        return fail(MIOPAL_ERR_HIP, "cannot allocate the upload bounce buffer");
-    }
+// Host -> device copies of database construction go through pinned bounce pieces owned by the
+// library, so that the runtime never pins (and keeps a mapping of) the caller's or the C library's
+// pageable memory: see Workspace::finishDownloads. The pieces are filled by a few host threads -
+// each with its own two pieces and its own stream, taking piece numbers from a counter - while
+// earlier pieces are on their way: gathering a million sequences from a million pointers
+// (the hand-off of opalSearchDatabase, src/pyopal/opal.pxd:38-52), checking every residue and
+// crossing PCIe overlap. Pieces are kept for the next database of the process (pinning memory
+// costs more than copying through it), up to kStagingKept of them.
+constexpr size_t kStagingPiece = (size_t)8 << 20;
+constexpr size_t kStagingKept = 8;   // kits: two pieces and two events each
+constexpr int kUploadStreams = 2;    // copies of all filling threads share these (see streamedUpload)
+
+struct UploadKit {
+    int device = -1;
+    void* piece[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
-    for (int k = 0; k < 2 && rc == 0; ++k)
-        if (hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess) rc = 1;
-    size_t off = 0;
-    for (int k = 0; off < bytes && rc == 0; ++k) {
-        const int b = k & 1;
-        const size_t nb = std::min(piece, bytes - off);
-        if (k >= 2 && hipEventSynchronize(done[b]) != hipSuccess) rc = 1;   // buffer b is free again
-        if (rc == 0) {
-            memcpy(bounce[b], (const char*)src + off, nb);
-            if (hipMemcpyAsync((char*)deviceDst + off, bounce[b], nb, hipMemcpyHostToDevice, s) != hipSuccess ||
-                hipEventRecord(done[b], s) != hipSuccess)
-                rc = 1;
-        }
-        off += nb;
+    ~UploadKit() {
+        for (hipEvent_t e : done)
+            if (e) (void)hipEventDestroy(e);
+        for (void* p : piece)
+            if (p) (void)hipHostFree(p);
     }
-    if (hipStreamSynchronize(s) != hipSuccess) rc = 1;
-    for (hipEvent_t e : done)
-        if (e) (void)hipEventDestroy(e);
-    cleanup();
-    if (rc) return fail(MIOPAL_ERR_HIP, "host to device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    bool second() {
+        if (piece[1]) return true;
+        if (hipHostMalloc(&piece[1], kStagingPiece, hipHostMallocPortable) != hipSuccess) (void)hipGetLastError();
+        return piece[1] != nullptr;
+    }
+};
+
+struct StagingPool {
+    std::mutex m;
+    std::vector<std::unique_ptr<UploadKit>> free;
+    // (the calling thread has made `device` current)
+    std::unique_ptr<UploadKit> take(int device, int* why) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t k = free.size(); k-- > 0;)
+                if (free[k]->device == device) {
+                    std::unique_ptr<UploadKit> kit = std::move(free[k]);
+                    free.erase(free.begin() + (long)k);
+                    return kit;
+                }
+        }
+        std::unique_ptr<UploadKit> kit(new UploadKit());
+        kit->device = device;
+        if (hipHostMalloc(&kit->piece[0], kStagingPiece, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            *why = 2;
+            return nullptr;
+        }
+        if (hipEventCreateWithFlags(&kit->done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&kit->done[1], hipEventDisableTiming) != hipSuccess) {
+            *why = 1;
+            return nullptr;
+        }
+        return kit;
+    }
+    void give(std::unique_ptr<UploadKit> kit) {
+        if (!kit) return;
+        std::lock_guard<std::mutex> g(m);
+        if (free.size() < kStagingKept) free.emplace_back(std::move(kit));
+    }
+    // the copy streams of one upload (idle ones of the device, or new ones)
+    struct StreamSet {
+        int device = -1;
+        hipStream_t s[kUploadStreams] = {};
+        ~StreamSet() {
+            for (hipStream_t x : s)
+                if (x) (void)hipStreamDestroy(x);
+        }
+    };
+    std::vector<std::unique_ptr<StreamSet>> freeStreams;
+    std::unique_ptr<StreamSet> takeStreams(int device) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t k = freeStreams.size(); k-- > 0;)
+                if (freeStreams[k]->device == device) {
+                    std::unique_ptr<StreamSet> set = std::move(freeStreams[k]);
+                    freeStreams.erase(freeStreams.begin() + (long)k);
+                    return set;
+                }
+        }
+        std::unique_ptr<StreamSet> set(new StreamSet());
+        set->device = device;
+        for (hipStream_t& x : set->s)
+            if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return set;
+    }
+    void giveStreams(std::unique_ptr<StreamSet> set) {
+        if (!set) return;
+        std::lock_guard<std::mutex> g(m);
+        if (freeStreams.size() < 4) freeStreams.emplace_back(std::move(set));
+    }
+};
+StagingPool& stagingPool() {
+    static StagingPool* pool = new StagingPool();   // never destroyed: the runtime may be gone at exit
+    return *pool;
+}
+
+// dst[0..n) = src[0..n), and the largest byte seen folded into `top` (16 lanes) / `topTail`
+typedef unsigned char Bytes16 __attribute__((vector_size(16)));
+inline void copyWithMax(unsigned char* dst, const unsigned char* src, size_t n, Bytes16& top, unsigned& topTail) {
+    if (n < 16) {
+        for (size_t i = 0; i < n; ++i) {
+            dst[i] = src[i];
+            topTail = std::max<unsigned>(topTail, src[i]);
+        }
+        return;
+    }
+    Bytes16 t = top;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        Bytes16 a, b, c, d;
+        memcpy(&a, src + i, 16);
+        memcpy(&b, src + i + 16, 16);
+        memcpy(&c, src + i + 32, 16);
+        memcpy(&d, src + i + 48, 16);
+        memcpy(dst + i, &a, 16);
+        memcpy(dst + i + 16, &b, 16);
+        memcpy(dst + i + 32, &c, 16);
+        memcpy(dst + i + 48, &d, 16);
+        t = __builtin_elementwise_max(t, __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d)));
+    }
+    for (; i + 16 <= n; i += 16) {
+        Bytes16 a;
+        memcpy(&a, src + i, 16);
+        memcpy(dst + i, &a, 16);
+        t = __builtin_elementwise_max(t, a);
+    }
+    if (i < n) {   // the last, overlapping 16 bytes
+        Bytes16 a;
+        memcpy(&a, src + n - 16, 16);
+        memcpy(dst + n - 16, &a, 16);
+        t = __builtin_elementwise_max(t, a);
+    }
+    top = t;
+}
+inline unsigned largestByte(const Bytes16& top, unsigned topTail) {
+    unsigned m = topTail;
+    for (int i = 0; i < 16; ++i) m = std::max<unsigned>(m, top[i]);
+    return m;
+}
+
+int uploadThreads(size_t bytes) {
+    // (one stream each: beyond the runtime's four hardware queues a stream's first copy waits for the others)
+    int t = (int)std::min<size_t>(4, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* env = getenv("MIOPAL_UPLOAD_THREADS")) t = std::max(1, std::min(64, atoi(env)));
+    const size_t pieces = (bytes + kStagingPiece - 1) / kStagingPiece;
+    return (int)std::max<size_t>(1, std::min<size_t>((size_t)t, pieces));
+}
+
+// fill(dst, offset, n): writes bytes [offset, offset + n) of the source into dst, returns 0 or a
+// positive code of its own (handed back through fillCode); called from several threads, on
+// disjoint ranges.
+template <class Fill>
+int streamedUpload(int device, void* deviceDst, size_t bytes, const Fill& fill, int* fillCode = nullptr) {
+    if (fillCode) *fillCode = 0;
+    if (bytes == 0) return 0;
+    const size_t pieces = (bytes + kStagingPiece - 1) / kStagingPiece;
+    const int nThreads = uploadThreads(bytes);
+    const bool timed = getenv("MIOPAL_PHASE_TIMING") != nullptr && bytes > (64u << 20);
+    // All copies go down a couple of streams shared by the filling threads: the runtime multiplexes
+    // streams onto four hardware queues, and with a stream per thread (beside those of the searches)
+    // the first copy of an unlucky stream was seen to wait 14 ms for the others to finish.
+    if (hipSetDevice(device) != hipSuccess) return fail(MIOPAL_ERR_HIP, "hipSetDevice(%d) failed", device);
+    std::unique_ptr<StagingPool::StreamSet> streams = stagingPool().takeStreams(device);
+    if (!streams) return fail(MIOPAL_ERR_HIP, "cannot create the upload streams");
+    int nStreams = kUploadStreams;
+    if (const char* env = getenv("MIOPAL_UPLOAD_STREAMS")) nStreams = std::max(1, std::min(kUploadStreams, atoi(env)));
+    std::atomic<int> workers{0};
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};     // 1: HIP, 2: out of pinned memory, otherwise the fill's code << 2
+    auto work = [&]() {
+        const double tStart = timed ? PhaseTimer::now() : 0;
+        double tWait = 0, tFill = 0, tCall = 0;
+        if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
+        int why = 0;
+        std::unique_ptr<UploadKit> kit = stagingPool().take(device, &why);
+        if (!kit) { failed.store(why); return; }
+        const double tSetup = timed ? PhaseTimer::now() : 0;
+        hipStream_t stream = streams->s[workers.fetch_add(1) % nStreams];
+        int inFlight = 0;    // bit b: piece b has a copy under way
+        for (int k = 0; failed.load(std::memory_order_relaxed) == 0; ++k) {
+            const size_t p = next.fetch_add(1);
+            if (p >= pieces) break;
+            const int b = k & 1;
+            if (b == 1 && !kit->second()) { failed.store(2); break; }
+            const double ta = timed ? PhaseTimer::now() : 0;
+            if (k >= 2 && hipEventSynchronize(kit->done[b]) != hipSuccess) { failed.store(1); break; }
+            const double tb = timed ? PhaseTimer::now() : 0;
+            const size_t off = p * kStagingPiece, n = std::min(kStagingPiece, bytes - off);
+            if (const int rc = fill((unsigned char*)kit->piece[b], off, n)) { failed.store(rc << 2); break; }
+            const double tc = timed ? PhaseTimer::now() : 0;
+            if (hipMemcpyAsync((char*)deviceDst + off, kit->piece[b], n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+                hipEventRecord(kit->done[b], stream) != hipSuccess) {
+                failed.store(1);
+                break;
+            }
+            inFlight |= 1 << b;
+            if (timed) {
+                const double td = PhaseTimer::now();
+                tWait += tb - ta; tFill += tc - tb; tCall += td - tc;
+            }
+        }
+        const double te = timed ? PhaseTimer::now() : 0;
+        // (the pieces go back to the pool only when their copies have left them)
+        for (int b = 0; b < 2; ++b)
+            if ((inFlight >> b & 1) && hipEventSynchronize(kit->done[b]) != hipSuccess) {
+                failed.store(1);
+                (void)hipStreamSynchronize(stream);
+            }
+        if (timed)
+            fprintf(stderr, "[miopal]   upload thread: setup %.2f wait %.2f fill %.2f enqueue %.2f drain %.2f ms\n",
+                    (tSetup - tStart) * 1e3, tWait * 1e3, tFill * 1e3, tCall * 1e3, (PhaseTimer::now() - te) * 1e3);
+        stagingPool().give(std::move(kit));
+    };
+    if (nThreads == 1) {
+        work();
+    } else {
+        std::vector<std::thread> pool;
+        pool.reserve((size_t)nThreads);
+        for (int t = 0; t < nThreads; ++t) pool.emplace_back(work);
+        for (auto& t : pool) t.join();
+    }
+    for (int k = 0; k < nStreams; ++k)
+        if (hipStreamSynchronize(streams->s[k]) != hipSuccess) failed.store(1);
+    if (failed.load() != 1) stagingPool().giveStreams(std::move(streams));
+    const int f = failed.load();
+    if (f == 1) return fail(MIOPAL_ERR_HIP, "host to device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    if (f == 2) return fail(MIOPAL_ERR_HIP, "cannot allocate the upload bounce buffer");
+    if (fillCode) *fillCode = f >> 2;   // (worker threads cannot leave a message: the caller words it)
     return 0;
+}
+
+int uploadOnce(int device, void* deviceDst, const void* src, size_t bytes) {
+    return streamedUpload(device, deviceDst, bytes, [src](unsigned char* dst, size_t off, size_t n) {
+        memcpy(dst, (const char*)src + off, n);
+        return 0;
+    });
 }
 
 // A staging channel of the handle for the duration of one view construction.
@@ -542,61 +745,152 @@ int dbLen(const MiopalDb* db, int64_t id) { return (int)(db->offsets[id + 1] - d
 // query can have in the target) every alignment lies inside one window [k S, k S + S + O).
 int segmentStride(int overlap) { return std::max(256, (overlap * 3 / 5 + 63) / 64 * 64); }
 
+// Host loops over a million targets (view lists, result structs) are cut into slices worked on by
+// a few threads; MIOPAL_HOST_THREADS overrides the count (default: up to 4).
+int hostThreads(size_t items, size_t perThread) {
+    int t = (int)std::min<size_t>(4, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* env = getenv("MIOPAL_HOST_THREADS")) t = std::max(1, std::min(64, atoi(env)));
+    return (int)std::max<size_t>(1, std::min<size_t>((size_t)t, items / std::max<size_t>(perThread, 1)));
+}
+template <class Body>
+void parallelSlices(int nSlices, const Body& body) {
+    if (nSlices <= 1) {
+        body(0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)nSlices - 1);
+    for (int t = 1; t < nSlices; ++t) pool.emplace_back([&body, t] { body(t); });
+    body(0);
+    for (auto& th : pool) th.join();
+}
+
+// A device block for a view: one left behind by the views of the handle's previous filling when it
+// fits without wasting more than half of itself, a fresh allocation otherwise.
+constexpr size_t kSpareBlocks = 4;
+int viewBlock(MiopalDb* db, size_t bytes, void** out, size_t* cap) {
+    {
+        std::lock_guard<std::mutex> g(db->viewMutex);
+        auto best = db->spareBlocks.end();
+        for (auto it = db->spareBlocks.begin(); it != db->spareBlocks.end(); ++it)
+            if (it->second >= bytes && it->second / 2 <= bytes + 4096 && (best == db->spareBlocks.end() || it->second < best->second))
+                best = it;
+        if (best != db->spareBlocks.end()) {
+            *out = best->first;
+            *cap = best->second;
+            db->spareBlocks.erase(best);
+            return 0;
+        }
+    }
+    HIP_TRY(hipMalloc(out, bytes));
+    *cap = bytes;
+    return 0;
+}
+
 int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
+    PhaseTimer pt;
     auto v = std::make_shared<View>();
     v->start = start;
     v->end = end;
     v->overlap = overlap;
-    std::vector<int32_t> ids, segStart, vlen;
-    ids.reserve((size_t)(end - start));
-    if (overlap > 0) {
-        const int stride = segmentStride(overlap), window = stride + overlap;
-        for (int64_t k = start; k < end; ++k) {
-            const int L = dbLen(db, k);
-            if (L <= window) {
-                ids.push_back((int32_t)k);
-                segStart.push_back(0);
-                vlen.push_back(L);
-                continue;
-            }
-            // windows until the tail is inside the overlap of the previous one
-            for (int s = 0; s == 0 || L - s > overlap; s += stride) {
-                ids.push_back((int32_t)k);
-                segStart.push_back(s);
-                vlen.push_back(std::min(window, L - s));
-            }
-        }
-    } else {
-        for (int64_t k = start; k < end; ++k) {
-            const int L = dbLen(db, k);
-            if (L > kLongTarget) {
-                v->longIds.push_back((int32_t)k);
-            } else {
-                ids.push_back((int32_t)k);
-                vlen.push_back(L);
-            }
-        }
-    }
-    {
-        // longest first: the heaviest wavefronts are dispatched first. Stable counting sort by
-        // length (windows of one target stay in order): O(n), where std::stable_sort cost most
-        // of the view construction for a million targets.
+    // The view's entries (targets, or windows of long targets), longest first: the heaviest
+    // wavefronts are dispatched first. A stable counting sort by length (windows of one target stay
+    // in order), in slices of the target range worked on side by side: count, place, scatter. For
+    // a million targets the lists used to cost more than the search itself.
+    const int64_t nT = end - start;
+    const int stride = overlap > 0 ? segmentStride(overlap) : 0, window = stride + overlap;
+    const int nSlices = hostThreads((size_t)nT, 65536);
+    auto sliceLo = [&](int t) { return start + nT * t / nSlices; };
+    auto windowsOf = [&](int L) {   // windows until the tail is inside the overlap of the previous one
+        if (L <= window) return 1;
+        return 1 + (L - overlap - 1) / stride;
+    };
+    std::vector<int64_t> sliceEntries((size_t)nSlices + 1, 0);
+    std::vector<int> sliceLongest((size_t)nSlices, 0);
+    std::vector<std::vector<int32_t>> sliceLong((size_t)nSlices);
+    parallelSlices(nSlices, [&](int t) {
+        int64_t entries = 0;
         int longest = 0;
-        for (int32_t L : vlen) longest = std::max(longest, L);
-        std::vector<int64_t> first((size_t)longest + 2, 0);
-        for (int32_t L : vlen) ++first[(size_t)(longest - L) + 1];
-        for (size_t b = 1; b < first.size(); ++b) first[b] += first[b - 1];
-        std::vector<int32_t> ids2(ids.size()), seg2(segStart.size()), len2(ids.size());
-        for (size_t x = 0; x < ids.size(); ++x) {
-            const size_t at = (size_t)first[(size_t)(longest - vlen[x])]++;
-            ids2[at] = ids[x];
-            len2[at] = vlen[x];
-            if (!segStart.empty()) seg2[at] = segStart[x];
+        for (int64_t k = sliceLo(t); k < sliceLo(t + 1); ++k) {
+            const int L = dbLen(db, k);
+            if (overlap > 0) {
+                entries += windowsOf(L);
+                longest = std::max(longest, std::min(L, window));
+            } else if (L > kLongTarget) {
+                sliceLong[(size_t)t].push_back((int32_t)k);
+            } else {
+                ++entries;
+                longest = std::max(longest, L);
+            }
         }
-        ids.swap(ids2);
-        segStart.swap(seg2);
-        vlen.swap(len2);
+        sliceEntries[(size_t)t + 1] = entries;
+        sliceLongest[(size_t)t] = longest;
+    });
+    pt.mark("view: count");
+    int longest = 0;
+    for (int t = 0; t < nSlices; ++t) {
+        sliceEntries[(size_t)t + 1] += sliceEntries[(size_t)t];
+        longest = std::max(longest, sliceLongest[(size_t)t]);
+        v->longIds.insert(v->longIds.end(), sliceLong[(size_t)t].begin(), sliceLong[(size_t)t].end());
     }
+    const size_t nEntries = (size_t)sliceEntries[(size_t)nSlices];
+    if (nEntries >= (size_t)INT32_MAX) return fail(MIOPAL_ERR_BAD_ARGUMENT, "too many windows in one view");
+    const size_t nBins = (size_t)longest + 1;
+    // place[t][b]: first sorted position of slice t's entries of length longest - b
+    std::vector<int64_t> place((size_t)nSlices * nBins, 0);
+    parallelSlices(nSlices, [&](int t) {
+        int64_t* mine = place.data() + (size_t)t * nBins;
+        for (int64_t k = sliceLo(t); k < sliceLo(t + 1); ++k) {
+            const int L = dbLen(db, k);
+            if (overlap > 0) {
+                if (L <= window) {
+                    ++mine[longest - L];
+                } else {
+                    const int w = windowsOf(L);
+                    mine[longest - window] += w - 1;
+                    ++mine[longest - std::min(window, L - (w - 1) * stride)];
+                }
+            } else if (L <= kLongTarget) {
+                ++mine[longest - L];
+            }
+        }
+    });
+    pt.mark("view: histogram");
+    {
+        int64_t running = 0;
+        for (size_t bin = 0; bin < nBins; ++bin)
+            for (int t = 0; t < nSlices; ++t) {
+                int64_t& c = place[(size_t)t * nBins + bin];
+                const int64_t n = c;
+                c = running;
+                running += n;
+            }
+    }
+    pt.mark("view: places");
+    const int nGroupsAll = (int)((nEntries + kGroupTargets - 1) / kGroupTargets);
+    std::vector<int32_t> ids(nEntries), segStart(overlap > 0 ? nEntries : 0);
+    std::vector<int32_t> vlen((size_t)nGroupsAll * kGroupTargets);   // padded to whole groups with zeros
+    parallelSlices(nSlices, [&](int t) {
+        int64_t* mine = place.data() + (size_t)t * nBins;
+        for (int64_t k = sliceLo(t); k < sliceLo(t + 1); ++k) {
+            const int L = dbLen(db, k);
+            if (overlap > 0) {
+                const int w = windowsOf(L);
+                for (int x = 0; x < w; ++x) {
+                    const int s0 = x * stride, len = w == 1 ? L : std::min(window, L - s0);
+                    const size_t at = (size_t)mine[longest - len]++;
+                    ids[at] = (int32_t)k;
+                    segStart[at] = s0;
+                    vlen[at] = len;
+                }
+            } else if (L <= kLongTarget) {
+                const size_t at = (size_t)mine[longest - L]++;
+                ids[at] = (int32_t)k;
+                vlen[at] = L;
+            }
+        }
+    });
+    pt.mark("view: scatter");
     v->nPacked = (int)ids.size();
     v->nGroups = (v->nPacked + kGroupTargets - 1) / kGroupTargets;
     std::vector<int64_t> groupOff(v->nGroups + 1, 0), chunkPrefix(v->nGroups + 1, 0), boundaryOff(v->nGroups + 1, 0);
@@ -612,19 +906,16 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
     }
     v->totalChunks = chunkPrefix[v->nGroups];
     v->groupChunksHost.assign(groupChunks.begin(), groupChunks.begin() + v->nGroups);
-    v->ids = ids;
     if (v->nGroups > 0) {
         // Two device allocations and one staged upload per view: the small per-target and per-group
         // arrays share one blob (hipMalloc, hipHostMalloc and stream creation serialise in the
         // runtime, and thread-chunked callers build their slices' views side by side).
         const size_t packBytes = (size_t)groupOff[v->nGroups] * sizeof(uint2);
-        std::vector<int32_t> lens((size_t)v->nGroups * kGroupTargets, 0);
-        for (size_t k = 0; k < ids.size(); ++k) lens[k] = vlen[k];
         struct Part { const void* src; size_t bytes, at; };
         Part parts[] = {
             {ids.data(), ids.size() * sizeof(int32_t), 0},
             {segStart.data(), overlap > 0 ? segStart.size() * sizeof(int32_t) : 0, 0},
-            {lens.data(), lens.size() * sizeof(int32_t), 0},
+            {vlen.data(), vlen.size() * sizeof(int32_t), 0},
             {groupOff.data(), groupOff.size() * sizeof(int64_t), 0},
             {groupChunks.data(), groupChunks.size() * sizeof(int), 0},
             {boundaryOff.data(), boundaryOff.size() * sizeof(int64_t), 0},
@@ -635,8 +926,10 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
             p.at = metaBytes;
             metaBytes += (p.bytes + 255) & ~(size_t)255;
         }
-        HIP_TRY(hipMalloc(&v->d_meta, std::max<size_t>(metaBytes, 256)));
-        HIP_TRY(hipMalloc(&v->d_pack, packBytes));
+        pt.mark("view: host lists");
+        RC_TRY(viewBlock(db, std::max<size_t>(metaBytes, 256), &v->d_meta, &v->metaCap));
+        RC_TRY(viewBlock(db, packBytes, (void**)&v->d_pack, &v->packCap));
+        pt.mark("view: device allocation");
         char* meta = (char*)v->d_meta;
         v->d_ids = (int32_t*)(meta + parts[0].at);
         v->d_segStart = overlap > 0 ? (int32_t*)(meta + parts[1].at) : nullptr;
@@ -665,8 +958,10 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
         // (the channel's own stream, and a wait for that stream only: other threads' searches go on)
         HIP_TRY(launchPack(pa, v->totalChunks, up.ch->stream));
         HIP_TRY(hipStreamSynchronize(up.ch->stream));
+        pt.mark("view: upload + pack");
         v->deviceBytes = packBytes + metaBytes;
     }
+    v->ids = std::move(ids);
     *out = v;
     return 0;
 }
@@ -1379,8 +1674,14 @@ int validate(const MiopalDb* db, const unsigned char* query, int Q, const int* m
     return 0;
 }
 
-int createCommon(MiopalDb** out, const unsigned char* residues, const std::vector<int64_t>& offsets,
-                 int64_t count, int alphabetLength, int device) {
+// The database's residues as the caller holds them: one flat array, or one pointer per sequence
+// (opalSearchDatabase's `unsigned char* db[]`).
+struct ResidueSource {
+    const unsigned char* flat = nullptr;
+    const unsigned char* const* sequences = nullptr;
+};
+
+int newHandle(std::unique_ptr<MiopalDb>* out, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(OPAL_ERR_NO_SIMD_SUPPORT, "no HIP device available");
@@ -1388,29 +1689,122 @@ int createCommon(MiopalDb** out, const unsigned char* residues, const std::vecto
     HIP_TRY(hipSetDevice(device));
     std::unique_ptr<MiopalDb> db(new MiopalDb());
     db->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        db->computeUnits = prop.multiProcessorCount;
+    // cached packed views may take a third of the device's memory (MIOPAL_VIEW_CACHE_MB overrides)
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) db->viewBudgetBytes = totalB / 3;
+    if (const char* mb = getenv("MIOPAL_VIEW_CACHE_MB")) db->viewBudgetBytes = (size_t)std::max(0, atoi(mb)) << 20;
+    *out = std::move(db);
+    return 0;
+}
+
+// (Re)fills a handle nobody else is using: the sequences replace whatever it held; device
+// allocations that are large enough stay, the blocks of its cached views are kept for the new views.
+int fillHandle(MiopalDb* db, const ResidueSource& src, std::vector<int64_t>&& offsets, int64_t count,
+               int alphabetLength) {
+    const int device = db->device;
+    HIP_TRY(hipSetDevice(device));
     {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            db->computeUnits = prop.multiProcessorCount;
-        // cached packed views may take a third of the device's memory (MIOPAL_VIEW_CACHE_MB overrides)
-        size_t freeB = 0, totalB = 0;
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB > 0) db->viewBudgetBytes = totalB / 3;
-        if (const char* mb = getenv("MIOPAL_VIEW_CACHE_MB")) db->viewBudgetBytes = (size_t)std::max(0, atoi(mb)) << 20;
+        std::lock_guard<std::mutex> g(db->viewMutex);
+        for (auto& slot : db->views) {
+            View* v = slot.view.get();
+            if (!v || slot.view.use_count() != 1) continue;
+            for (auto blk : {std::make_pair((void**)&v->d_pack, v->packCap), std::make_pair(&v->d_meta, v->metaCap)})
+                if (*blk.first && db->spareBlocks.size() < kSpareBlocks) {
+                    db->spareBlocks.emplace_back(*blk.first, blk.second);
+                    *blk.first = nullptr;
+                }
+        }
+        db->views.clear();
     }
     db->alphabet = alphabetLength;
     db->count = count;
-    db->offsets = offsets;
-    db->total = offsets[(size_t)count];
-    for (int64_t k = 0; k < count; ++k) db->maxLen = std::max(db->maxLen, offsets[(size_t)k + 1] - offsets[(size_t)k]);
-    for (int64_t i = 0; i < db->total; ++i)
-        if (residues[i] >= alphabetLength)
-            return fail(MIOPAL_ERR_BAD_ARGUMENT, "residue %d out of range for alphabet %d", residues[i], alphabetLength);
-    HIP_TRY(hipMalloc(&db->d_residues, (size_t)db->total + 64));
-    HIP_TRY(hipMalloc(&db->d_offsets, (size_t)(count + 1) * sizeof(int64_t)));
-    RC_TRY(uploadOnce(db->d_residues, residues, (size_t)db->total));
-    RC_TRY(uploadOnce(db->d_offsets, offsets.data(), (size_t)(count + 1) * sizeof(int64_t)));
+    db->offsets = std::move(offsets);
+    const std::vector<int64_t>& off = db->offsets;
+    db->total = off[(size_t)count];
+    db->maxLen = 0;
+    for (int64_t k = 0; k < count; ++k) db->maxLen = std::max(db->maxLen, off[(size_t)k + 1] - off[(size_t)k]);
+    const size_t wantRes = (size_t)db->total + 64, wantOff = (size_t)(count + 1) * sizeof(int64_t);
+    if (db->residueCap < wantRes || db->residueCap / 4 > wantRes + (1u << 20)) {
+        if (db->d_residues) HIP_TRY(hipFree(db->d_residues));
+        db->d_residues = nullptr;
+        db->residueCap = 0;
+        HIP_TRY(hipMalloc(&db->d_residues, wantRes));
+        db->residueCap = wantRes;
+    }
+    if (db->offsetsCap < wantOff || db->offsetsCap / 4 > wantOff + (1u << 20)) {
+        if (db->d_offsets) HIP_TRY(hipFree(db->d_offsets));
+        db->d_offsets = nullptr;
+        db->offsetsCap = 0;
+        HIP_TRY(hipMalloc(&db->d_offsets, wantOff));
+        db->offsetsCap = wantOff;
+    }
+    // residues: gathered (or copied) piece by piece into the bounce pieces and checked there
+    const unsigned limit = (unsigned)alphabetLength;
+    int bad = 0;
+    RC_TRY(streamedUpload(device, db->d_residues, (size_t)db->total,
+        [&](unsigned char* dst, size_t at, size_t n) {
+            Bytes16 top = {};
+            unsigned topTail = 0;
+            if (src.flat) {
+                copyWithMax(dst, src.flat + at, n, top, topTail);
+            } else {
+                // first sequence that ends beyond `at`
+                size_t k = (size_t)(std::upper_bound(off.begin(), off.begin() + count + 1, (int64_t)at) - off.begin()) - 1;
+                size_t pos = at;
+                const size_t stop = at + n;
+                while (pos < stop) {
+                    const size_t seqEnd = (size_t)off[k + 1];
+                    if (seqEnd <= pos) { ++k; continue; }   // (empty sequences)
+                    const size_t m = std::min(seqEnd, stop) - pos;
+                    copyWithMax(dst + (pos - at), src.sequences[k] + (pos - (size_t)off[k]), m, top, topTail);
+                    pos += m;
+                }
+            }
+            const unsigned largest = largestByte(top, topTail);
+            return largest >= limit ? (int)largest + 1 : 0;
+        }, &bad));
+    if (bad) return fail(MIOPAL_ERR_BAD_ARGUMENT, "residue %d out of range for alphabet %d", bad - 1, alphabetLength);
+    RC_TRY(uploadOnce(device, db->d_offsets, off.data(), wantOff));
+    return 0;
+}
+
+int createCommon(MiopalDb** out, const ResidueSource& src, std::vector<int64_t>&& offsets,
+                 int64_t count, int alphabetLength, int device) {
+    std::unique_ptr<MiopalDb> db;
+    RC_TRY(newHandle(&db, device));
+    RC_TRY(fillHandle(db.get(), src, std::move(offsets), count, alphabetLength));
     *out = db.release();
     return 0;
+}
+
+// Handles of finished opalSearchDatabase calls, kept (with their device memory, bounce buffers and
+// streams) for the next call of the process: the reference's entry point hands the whole database
+// over on every call, and allocating and releasing a handle's resources costs as much as the search.
+// Bounded by count and by the device memory a parked handle may hold (MIOPAL_SPARE_HANDLE_MB,
+// default 4096; 0 keeps none); miopalReleaseCaches() drops them.
+constexpr size_t kSpareHandles = 4;
+struct SpareHandles {
+    std::mutex m;
+    std::vector<std::unique_ptr<MiopalDb>> idle;
+};
+SpareHandles& spareHandles() {
+    static SpareHandles* s = new SpareHandles();   // never destroyed: the runtime may be gone at exit
+    return *s;
+}
+
+int64_t handleDeviceBytes(MiopalDb* db) {
+    int64_t t = (int64_t)(db->residueCap + db->offsetsCap);
+    {
+        std::lock_guard<std::mutex> g(db->viewMutex);
+        for (auto& v : db->views) t += v.view ? (int64_t)(v.view->packCap + v.view->metaCap) : 0;
+        for (auto& b : db->spareBlocks) t += (int64_t)b.second;
+    }
+    std::lock_guard<std::mutex> g(db->wsMutex);
+    for (auto& w : db->ownedFree) t += (int64_t)w->bytes();
+    return t;
 }
 
 }  // namespace
@@ -1445,10 +1839,11 @@ int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const 
         if (lengths[k] < 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "negative sequence length");
         offsets[(size_t)k + 1] = offsets[(size_t)k] + lengths[k];
     }
-    std::vector<unsigned char> flat((size_t)offsets[(size_t)count] + 1);
     for (int64_t k = 0; k < count; ++k)
-        if (lengths[k]) memcpy(flat.data() + offsets[(size_t)k], sequences[k], (size_t)lengths[k]);
-    return createCommon(out, flat.data(), offsets, count, alphabetLength, device);
+        if (lengths[k] > 0 && !sequences[k]) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null sequence %lld", (long long)k);
+    ResidueSource src;
+    src.sequences = sequences;
+    return createCommon(out, src, std::move(offsets), count, alphabetLength, device);
 }
 
 int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int64_t* offsets,
@@ -1463,10 +1858,30 @@ int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int6
         if (off[(size_t)k + 1] < off[(size_t)k] || off[(size_t)k + 1] - off[(size_t)k] > INT32_MAX)
             return fail(MIOPAL_ERR_BAD_ARGUMENT, "offsets must be non-decreasing");
     if (off[(size_t)count] > 0 && !residues) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null residues");
-    return createCommon(out, residues, off, count, alphabetLength, device);
+    ResidueSource src;
+    src.flat = residues;
+    return createCommon(out, src, std::move(off), count, alphabetLength, device);
 }
 
 void miopalDbDestroy(MiopalDb* db) { delete db; }
+
+void miopalReleaseCaches(void) {
+    std::vector<std::unique_ptr<MiopalDb>> handles;
+    {
+        SpareHandles& sp = spareHandles();
+        std::lock_guard<std::mutex> g(sp.m);
+        handles.swap(sp.idle);
+    }
+    handles.clear();
+    std::vector<std::unique_ptr<UploadKit>> kits;
+    {
+        StagingPool& pool = stagingPool();
+        std::lock_guard<std::mutex> g(pool.m);
+        kits.swap(pool.free);
+        pool.freeStreams.clear();
+    }
+    kits.clear();
+}
 
 int64_t miopalDbCount(const MiopalDb* db) { return db ? db->count : 0; }
 int64_t miopalDbTotalLength(const MiopalDb* db) { return db ? db->total : 0; }
@@ -1542,6 +1957,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         (!startTarget || !startQuery || (flat ? !flatOff : (!alignment || !alignmentLength))))
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
     HIP_TRY(hipSetDevice(db->device));
+    PhaseTimer pt;
     WorkspaceLease lease(db);
     RC_TRY(lease.acquireInternal());
     Workspace* ws = lease.ws;
@@ -1549,7 +1965,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     Search s{db, ws, stream, query, queryLength, gapOpen, gapExt, alphabetLength, searchType, mode,
              scoreMatrix, start, end, n};
     RC_TRY(s.prepare());
-    PhaseTimer pt;
+    pt.mark("workspace + query");
 
     void *ps, *pi = nullptr, *pj = nullptr;
     RC_TRY(ws->get(kScore, (size_t)n * sizeof(int32_t), &ps));
@@ -2134,22 +2550,27 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
         for (auto p : aln) free(p);
         return rc;
     }
-    for (int64_t k = 0; k < n; ++k) {
-        OpalSearchResult* r = results[k];
-        r->scoreSet = 1;
-        r->score = score[(size_t)k];
-        if (searchType >= OPAL_SEARCH_SCORE_END) {
-            r->endLocationTarget = et[(size_t)k];
-            r->endLocationQuery = eq[(size_t)k];
+    PhaseTimer pt;
+    const int nSlices = hostThreads((size_t)n, 65536);
+    parallelSlices(nSlices, [&](int t) {
+        for (int64_t k = n * t / nSlices; k < n * (t + 1) / nSlices; ++k) {
+            OpalSearchResult* r = results[k];
+            r->scoreSet = 1;
+            r->score = score[(size_t)k];
+            if (searchType >= OPAL_SEARCH_SCORE_END) {
+                r->endLocationTarget = et[(size_t)k];
+                r->endLocationQuery = eq[(size_t)k];
+            }
+            if (searchType == OPAL_SEARCH_ALIGNMENT) {
+                r->startLocationTarget = st[(size_t)k];
+                r->startLocationQuery = sq[(size_t)k];
+                r->alignment = alen[(size_t)k] > 0 ? aln[(size_t)k] : nullptr;
+                if (alen[(size_t)k] == 0) free(aln[(size_t)k]);
+                r->alignmentLength = alen[(size_t)k];
+            }
         }
-        if (searchType == OPAL_SEARCH_ALIGNMENT) {
-            r->startLocationTarget = st[(size_t)k];
-            r->startLocationQuery = sq[(size_t)k];
-            r->alignment = alen[(size_t)k] > 0 ? aln[(size_t)k] : nullptr;
-            if (alen[(size_t)k] == 0) free(aln[(size_t)k]);
-            r->alignmentLength = alen[(size_t)k];
-        }
-    }
+    });
+    pt.mark("result structs");
     return 0;
 }
 
@@ -2175,14 +2596,58 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
                        int alphabetLength, OpalSearchResult* results[], const int searchType, int mode,
                        int overflowMethod) {
     if (dbLength <= 0) return 0;
-    MiopalDb* h = nullptr;
     int device = 0;
     if (const char* env = getenv("MIOPAL_DEVICE")) device = atoi(env);
-    int rc = miopalDbCreate(&h, (const unsigned char* const*)db, dbSeqLengths, dbLength, alphabetLength, device);
-    if (rc) return rc;
-    rc = miopalSearchResults(h, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
-                             searchType, mode, overflowMethod, 0, dbLength);
-    miopalDbDestroy(h);
+    const bool verbose = getenv("MIOPAL_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!db || !dbSeqLengths) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to opalSearchDatabase");
+    if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
+        return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d not in 1..32", alphabetLength);
+    std::vector<int64_t> offsets((size_t)dbLength + 1, 0);
+    for (int k = 0; k < dbLength; ++k) {
+        if (dbSeqLengths[k] < 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "negative sequence length");
+        if (dbSeqLengths[k] > 0 && !db[k]) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null sequence %d", k);
+        offsets[(size_t)k + 1] = offsets[(size_t)k] + dbSeqLengths[k];
+    }
+    // a handle of an earlier call, or a new one
+    std::unique_ptr<MiopalDb> h;
+    {
+        SpareHandles& sp = spareHandles();
+        std::lock_guard<std::mutex> g(sp.m);
+        for (size_t k = sp.idle.size(); k-- > 0;)
+            if (sp.idle[k]->device == device) {
+                h = std::move(sp.idle[k]);
+                sp.idle.erase(sp.idle.begin() + (long)k);
+                break;
+            }
+    }
+    if (!h) RC_TRY(newHandle(&h, device));
+    ResidueSource src;
+    src.sequences = (const unsigned char* const*)db;
+    int rc = fillHandle(h.get(), src, std::move(offsets), dbLength, alphabetLength);
+    const auto t1 = std::chrono::steady_clock::now();
+    if (rc == 0)
+        rc = miopalSearchResults(h.get(), query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
+                                 searchType, mode, overflowMethod, 0, dbLength);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (rc == 0) {
+        int64_t keepMb = 4096;
+        if (const char* env = getenv("MIOPAL_SPARE_HANDLE_MB")) keepMb = atoll(env);
+        if (handleDeviceBytes(h.get()) <= (keepMb << 20)) {
+            SpareHandles& sp = spareHandles();
+            std::lock_guard<std::mutex> g(sp.m);
+            if (sp.idle.size() < kSpareHandles) sp.idle.emplace_back(std::move(h));
+        }
+    }
+    if (h) {
+        (void)hipSetDevice(h->device);
+        h.reset();
+    }
+    if (verbose) {
+        const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "miopal: opalSearchDatabase: upload %.1f ms, search + results %.1f ms, release %.1f ms\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
+    }
     return rc;
 }
 
