@@ -126,7 +126,8 @@ int miopalLastKernelTime(MiopalDb* db, float* ms);
  *   counts[0] targets computed by the wavefront-per-pair (int32) kernel
  *   counts[1] kernel of the lane-per-target pass, low four bits: 0 none, 1 general (v_perm profile), 2 / 3 / 4
  *             pair table with int16 / half-float / biased-integer lanes (Smith-Waterman), 5 pair table for
- *             NW / HW / OV; + 16 when the pair-table launch was refused and the general kernel ran instead;
+ *             NW / HW / OV, 6 pair table strip by strip (Smith-Waterman scores of several strips); + 16 when the
+ *             pair-table launch was refused and the general kernel ran instead;
  *             + 32 x the general kernel's lane arithmetic (0 half floats, 1 int16, 2 signed int16, 4 / 5
  *             anti-diagonally shifted signed / unsigned, 6 column-shifted unsigned Smith-Waterman)
  *   counts[2] groups given to the main lane-per-target kernel

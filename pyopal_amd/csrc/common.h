@@ -49,6 +49,7 @@ struct InterseqArgs {
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
+    int batchGroups;           // strips kernel: groups a workgroup sweeps side by side (1..12; fewer when the groups are few)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -174,7 +175,8 @@ enum PairFlavour : int {
     kPairSwInt16 = 0,   // saturating int16
     kPairSwHalf = 1,    // packed half floats, exact below 2048
     kPairSwBiased = 2,  // biased integer halves compared as half floats, column-shifted (interseq_impl.h)
-    kPairGlobalBiased = 3  // NW / HW / OV on the same representation (scores, optional end locations)
+    kPairGlobalBiased = 3, // NW / HW / OV on the same representation (scores, optional end locations)
+    kPairSwStrips = 4      // Smith-Waterman scores of several strips on biased halves (units of (batch, strip))
 };
 // limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
 constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
@@ -193,6 +195,8 @@ hipError_t launchInterseqPairSwBiasedA(const InterseqArgs& a, int rows, int comp
 hipError_t launchInterseqPairSwBiasedB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwBiasedD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwStripsA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

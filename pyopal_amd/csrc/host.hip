@@ -1049,6 +1049,7 @@ struct Search {
     int maxScore = 0, minScore = 0;
     int64_t balancedChunks = 0;
     bool globalPairRefused = false;   // the pair-table launch for NW / HW / OV failed on this device
+    bool pairStripsRefused = false;   // the same for the multi-strip Smith-Waterman kernel
 
     uint8_t* d_query = nullptr;
     int32_t* d_matrix = nullptr;
@@ -1305,6 +1306,49 @@ struct Search {
                 waves = b;
             }
         }
+        // Smith-Waterman scores of more rows than one pair table holds: the pair-table kernel strip by
+        // strip (interseq_pair_strips_kernel: units of (batch of 12 groups, strip), boundary rows
+        // through HBM), when the scores and gap costs fit the biased halves' guard band. Strips of at
+        // most 52 rows (the kernel's register budget), all of the same even height.
+        int stripRows = 0;
+        {
+            const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
+            const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
+            const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
+            const bool band = up <= kBiasedMaxStepUp && down <= kBiasedMaxMagnitude && 5 * (int64_t)ext <= kLocMaxShift &&
+                              minScore > kBiasedPad;
+            const int single = std::max(2, (Q + 1) / 2 * 2);
+            const bool oneStrip = Q <= kLanes && interseqPairFits(single, A + 1);
+            int maxRows = 52;
+            while (maxRows >= 32 && !interseqPairFits(maxRows, A + 1)) maxRows -= 2;
+            if (mode == OPAL_MODE_SW && searchType == OPAL_SEARCH_SCORE && useHalf && band && !oneStrip && maxRows >= 32 &&
+                !pairStripsRefused && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
+                !getenv("MIOPAL_NO_PAIR_STRIPS") && !getenv("MIOPAL_STRIPS")) {
+                const int ns = std::max(2, (Q + maxRows - 1) / maxRows);
+                const int rowsP = ((Q + ns - 1) / ns + 1) / 2 * 2;
+                // Worth it when there are units enough to keep every CU on one strip for a while, or strips
+                // enough that the general kernel pays many rounds: measured on 2k .. 1M x 300, the strips
+                // kernel wins from about 2.5 units per CU on (+9 .. +24 %) and from 20 strips on at any
+                // size, and loses below (50k x 300 at Q = 300, 0.8 units per CU: 1.17 against 0.85 ms)
+                const int64_t units = (int64_t)((view->nGroups + 11) / 12) * ns;
+                // A wavefront sweeps a strip of ~50 rows at about a microsecond per column, whoever shares
+                // its CU (a batch is twelve neighbours of the length-sorted view: all long, or all short),
+                // where the general kernel pipelines a group's strips over the wavefronts of a workgroup
+                // at a third of that. The longest group must therefore be short against the launch, or
+                // it IS the launch: log-normal lengths, 500k targets at Q = 150, windows of 3072 columns:
+                // 5.3 ms against the general kernel's 2.9 ms.
+                int64_t totalChunks = 0;
+                for (int c : view->groupChunksHost) totalChunks += c;
+                const int64_t balanced = totalChunks * ns / ((int64_t)db->computeUnits * 12);
+                const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= balanced;
+                const bool enough = ((ns >= 16 || 2 * units >= 5 * (int64_t)db->computeUnits) && hidden) || getenv("MIOPAL_PAIR_STRIPS");
+                if (enough && rowsP >= 32 && rowsP <= maxRows && (int64_t)(ns - 1) * rowsP < Q && ns <= 4096) {
+                    stripRows = rowsP;
+                    nStrips = ns;
+                    waves = 1;   // (strips of a group in turn, each in its own unit)
+                }
+            }
+        }
         // A group keeps its wavefronts busy for (columns of its longest target) x (rounds of strips).
         // Groups far above the balanced share of a workgroup slot would stretch the kernel to
         // their own length (one lane per target cannot split a target), so the leading
@@ -1314,7 +1358,9 @@ struct Search {
         if (view->nGroups > 0) {
             int64_t total = 0;
             for (int c : view->groupChunksHost) total += c;
-            const int64_t slots = (int64_t)db->computeUnits * std::max(1, 12 / waves);
+            // (the strips kernel: 12 wavefronts per CU, a group's strips side by side in different ones)
+            const int64_t slots = stripRows ? std::max<int64_t>(1, (int64_t)db->computeUnits * 12 / nStrips)
+                                            : (int64_t)db->computeUnits * std::max(1, 12 / waves);
             // (2.5 x the balanced share; measured again in round 2 on the log-normal database, NW at
             // Q = 150: keeping the longest group in the packed kernel costs 5.6 ms against 4.0)
             int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
@@ -1330,7 +1376,8 @@ struct Search {
         g_lastRouting[2] = view->nGroups - firstGroup;
 
         if (view->nGroups > firstGroup) {
-            const int rows = (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
+            const bool pairStrips = stripRows > 0;
+            const int rows = pairStrips ? stripRows : (((Q + nStrips - 1) / nStrips) + 7) / 8 * 8;
             const int qPad = nStrips * rows;
             const int nSym = A + 1;
             // Lane arithmetic. Smith-Waterman: packed half floats are exact for integers
@@ -1369,7 +1416,7 @@ struct Search {
             // leaves a range worth having - zero + ext x columns + score below 0x7C00.
             int swBias = 0, swLimit = 0;
             bool swShifted = false;
-            if (sw && !locate && !usePair && useHalf && !getenv("MIOPAL_NO_SW_SHIFT")) {
+            if (sw && !locate && !usePair && !pairStrips && useHalf && !getenv("MIOPAL_NO_SW_SHIFT")) {
                 swBias = std::max(0, -(minScore + ext));                       // profile entries s + ext + K >= 0
                 const int64_t stepUp = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
                 const int64_t lim = 0x7C00 - kSwShiftZero - (int64_t)ext * (view->maxPackedLen + 8) -
@@ -1383,7 +1430,7 @@ struct Search {
             // Half floats turn a sum above 65504 into +inf, and inf + (-inf padding) into NaN, which
             // the flag `best >= 2048` would miss (NaN converts to 0): only matrices whose best
             // possible score stays finite take the half-float rung.
-            const bool halfFloat = sw && useHalf && !biased && !swShifted && maxScore <= 1024 && minScore >= -1024 &&
+            const bool halfFloat = sw && useHalf && !biased && !swShifted && !pairStrips && maxScore <= 1024 && minScore >= -1024 &&
                                    (int64_t)std::min<int64_t>(Q, db->maxLen) * std::max(maxScore, 0) < 60000;
             InterseqFlavour flavour = sw ? (swShifted ? kSwShifted : halfFloat ? kSwHalf : kSwInt16) : kSignedInt16;
             int profileShift = swShifted ? ext + swBias : 0;
@@ -1453,7 +1500,7 @@ struct Search {
                 return bits;
             };
             // (the unsigned shifted flavour: padding scores open - ext after the shift, see ArithU16Diag)
-            const int16_t padValue = (biased || globalPair) ? (int16_t)kBiasedPad
+            const int16_t padValue = (biased || globalPair || pairStrips) ? (int16_t)kBiasedPad
                                      : swShifted ? (int16_t)0   // s + ext + K = 0: a true score of -(ext + K) <= 0
                                      : flavour == kUnsignedDiag ? (int16_t)(open - ext)
                                      : halfFloat ? (int16_t)0xFC00 : (int16_t)-32768;
@@ -1492,7 +1539,7 @@ struct Search {
                 queryBest += rowMax;
             }
             const int64_t reach = std::min<int64_t>((int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0), queryBest);
-            const int64_t limit = biased ? biasedLimit : swShifted ? swLimit : halfFloat ? 2048 : 32767;
+            const int64_t limit = (biased || pairStrips) ? biasedLimit : swShifted ? swLimit : halfFloat ? 2048 : 32767;
             const bool mayOverflow = sw && reach >= limit;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
@@ -1543,7 +1590,18 @@ struct Search {
             const int64_t unitSlots = (int64_t)db->computeUnits * std::max(1, 8 / waves);
             const char* um = getenv("MIOPAL_UNITS");
             const bool wantUnits = um ? um[0] == '1' : (int64_t)(view->nGroups - firstGroup) < 6 * unitSlots;
-            if ((nStrips + waves - 1) / waves > 1 && !locate && !usePair && !globalPair && wantUnits) {
+            if (pairStrips) {
+                // unit counter + chunks published per (group, strip); scores and flags start from zero
+                // (a group's answer is the maximum over its strips' units)
+                void* us;
+                const size_t ints = (size_t)ia.nGroups * nStrips + 1;
+                RC_TRY(ws->get(kUnitState, ints * sizeof(int), &us));
+                HIP_TRY(hipMemsetAsync(us, 0, ints * sizeof(int), stream));
+                HIP_TRY(hipMemsetAsync(vs, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
+                HIP_TRY(hipMemsetAsync(vo, 0, (size_t)view->nGroups * kGroupTargets, stream));
+                ia.unitCounter = (int*)us;
+                ia.unitFlags = (int*)us + 1;
+            } else if ((nStrips + waves - 1) / waves > 1 && !locate && !usePair && !globalPair && wantUnits) {
                 void *us, *up;
                 const size_t ints = (size_t)ia.nGroups + 1;
                 RC_TRY(ws->get(kUnitState, ints * sizeof(int), &us));
@@ -1561,7 +1619,25 @@ struct Search {
                 HIP_TRY(hipEventRecord(e0, stream));
             }
             g_lastRouting[1] = 1 + 32 * (int)flavour;  // general kernel and its lane arithmetic
-            if (usePair || globalPair) {
+            if (pairStrips) {
+                int pairUnits = db->computeUnits;
+                if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
+                    pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
+                g_lastRouting[1] = 2 + (int)kPairSwStrips;
+                // few (group, strip) units: fewer groups per workgroup, so that every CU gets a unit and a
+                // wavefront shares its SIMD with fewer others
+                ia.batchGroups = (int)std::max<int64_t>(1, std::min<int64_t>(12, (int64_t)ia.nGroups * nStrips / std::max(1, pairUnits)));
+                const hipError_t pe = launchInterseqPair(ia, rows, kPairSwStrips, pairUnits, stream, false);
+                if (pe != hipSuccess) {
+                    // (e.g. the runtime refuses 150 KB of dynamic LDS: start over on the general kernel)
+                    (void)hipGetLastError();
+                    pairStripsRefused = true;
+                    if (getenv("MIOPAL_VERBOSE"))
+                        fprintf(stderr, "miopal: multi-strip pair-table kernel refused (%s), using the general kernel\n",
+                                hipGetErrorString(pe));
+                    return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
+                }
+            } else if (usePair || globalPair) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));
                 HIP_TRY(hipMemsetAsync(wc, 0, sizeof(int), stream));
@@ -1639,7 +1715,7 @@ struct Search {
                 int32_t count = 0;
                 RC_TRY(ws->stageDownload(&count, ct, sizeof(int32_t)));
                 RC_TRY(ws->finishDownloads());
-                if ((halfFloat || biased || swShifted) && count > kMaxDirectRecompute) {
+                if ((halfFloat || biased || swShifted || pairStrips) && count > kMaxDirectRecompute) {
                     // many targets left the half-float range: second rung, int16 lanes,
                     // over the whole view (its results overwrite the first pass)
                     return scorePassImpl(d_score, d_endI, d_endJ, false);

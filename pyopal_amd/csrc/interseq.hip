@@ -39,6 +39,7 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
                               hipStream_t stream, bool locate) {
     if (a.nGroups <= 0) return hipSuccess;
     if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased) return hipErrorInvalidValue;
+    if (a.nStrips != 1 && flavour != kPairSwStrips) return hipErrorInvalidValue;
     switch (flavour) {
         case kPairGlobalBiased:
             // (end locations are a run-time option of this kernel: a.endI != nullptr)
@@ -60,6 +61,10 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
             if (rowsPerStrip < 34) return launchInterseqPairSwBiasedB(a, rowsPerStrip, computeUnits, stream);
             if (rowsPerStrip < 50) return launchInterseqPairSwBiasedC(a, rowsPerStrip, computeUnits, stream);
             return launchInterseqPairSwBiasedD(a, rowsPerStrip, computeUnits, stream);
+        case kPairSwStrips:
+            if (rowsPerStrip < 32 || rowsPerStrip > 52 || (rowsPerStrip & 1)) return hipErrorInvalidValue;
+            if (rowsPerStrip < 48) return launchInterseqPairSwStripsA(a, rowsPerStrip, computeUnits, stream);
+            return launchInterseqPairSwStripsB(a, rowsPerStrip, computeUnits, stream);
         case kPairSwHalf: return launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream);
         case kPairSwInt16: return launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
     }

@@ -45,6 +45,8 @@
 #pragma once
 #include <algorithm>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace miopal {
@@ -1347,6 +1349,303 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
         case 10: return launchPairBiasedR<kLo + 10, LOC>(a, computeUnits, stream);
         case 12: return launchPairBiasedR<kLo + 12, LOC>(a, computeUnits, stream);
         case 14: return launchPairBiasedR<kLo + 14, LOC>(a, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- Smith-Waterman scores of SEVERAL strips on the pair table (round 2) -----------
+// The biased-halves kernel above for queries of more than one strip. A pair table holds one strip
+// of the query and fills the CU's LDS, so all twelve wavefronts of a workgroup work on the same
+// strip: a workgroup takes units (batch of 12 groups, strip) from a counter, strip-major, rebuilds
+// the table when the strip changes (150 KB of LDS writes, a few microseconds) and each wavefront
+// sweeps its group through that strip. The last row of a strip reaches the strip below through HBM: per column and
+// lane the pair (H, F) as patterns on that column's scale - both strips rebase their column shift at
+// the same chunks, so a pattern means the same in either - 512 bytes per column and wavefront,
+// written once and read once. The wavefront of (group, s) follows the wavefront of (group, s - 1) -
+// which may still be running in another workgroup when the batches are few - two chunks behind: the producer publishes the
+// number of finished chunks (release), the consumer acquires it before it fetches rows it has not
+// seen published. Every taken unit's producer was taken before it and strip 0 waits for nobody, so
+// the chain always moves; a consumer that nevertheless waits longer than about a second poisons its
+// own progress counter and flags its lanes, and the next rung recomputes them.
+// A group's maximum is the maximum over its strips: atomicMax into the (zeroed) view scores.
+#ifndef MIOPAL_STRIP_ROWS_AHEAD
+#define MIOPAL_STRIP_ROWS_AHEAD 2
+#endif
+#ifndef MIOPAL_STRIP_SLEEP
+#define MIOPAL_STRIP_SLEEP 8
+#endif
+#ifndef MIOPAL_STRIP_SLACK
+#define MIOPAL_STRIP_SLACK 0
+#endif
+constexpr int kStripPoison = 1 << 30;
+constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
+
+template <int R>
+__global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kernel(InterseqArgs a) {
+    constexpr int SLOTS = PairLayout<R>::kRowSlots;
+    constexpr int NB4 = (R + 3) / 4;
+    extern __shared__ uint4 pairs[];
+
+    const int lane = threadIdx.x & 63;
+    const int nSym = a.nSymbols;
+    const int ext = a.gapExt;
+    const uint32_t ext2 = both(ext), openMinusExt2 = both(a.gapOpen - ext);
+    const uint32_t zero2 = both(kBiasedZero);
+    const int nStrips = a.nStrips;
+    const int perBatch = a.batchGroups;   // 12, or fewer when the groups are few (more CUs, faster wavefronts)
+    const int nBatches = (a.nGroups + perBatch - 1) / perBatch;
+    int* ctl = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);   // 16 bytes behind the table
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tableStrip = -1;
+
+    for (;;) {
+        if (threadIdx.x == 0) ctl[0] = atomicAdd(a.unitCounter, 1);
+        __syncthreads();   // (and: every wavefront has left the table of the unit before)
+        const int u = __builtin_amdgcn_readfirstlane(ctl[0]);
+        if (u >= nBatches * nStrips) break;
+        // strip-major: strip s of every batch before strip s + 1 of any. The wavefront above is then
+        // (number of batches) units ahead - usually finished, never just started: with batch-major
+        // order every unit began by waiting for the unit taken a moment before it to get two chunks
+        // ahead, and a chain of 20 strips idled a fifth of the time - and a workgroup keeps its table
+        // until the strip changes.
+        const int s = u / nBatches, b = u - s * nBatches;
+        if (s != tableStrip) {
+            const int16_t* gp = a.profile + s * R;
+            uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
+            const int total = nSym * nSym * R;
+            for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
+                const int row = idx / R, r = idx - row * R;
+                const int tA = row / nSym, tB = row - tA * nSym;
+                const int sA = gp[tA * a.qPad + r] + ext, sB = gp[tB * a.qPad + r] + ext;
+                pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
+            }
+            tableStrip = s;
+        }
+        __syncthreads();   // table ready; ctl[0] read by everybody
+        const int gIdx = b * perBatch + wave;
+        if (wave >= perBatch || gIdx >= a.nGroups) continue;
+        const int g = gIdx + a.groupBase;
+        const uint2* pack = a.pack + a.groupOff[g];
+        const int nChunks = a.groupChunks[g];
+        // (a long group is the launch's critical path: it wins the SIMD's issue arbitration)
+        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        const bool fromAbove = s > 0, toBelow = s + 1 < nStrips;
+        // boundary rows: [column][lane] (H, F) of the strip's last row
+        // (wave-uniform bases and 32-bit element offsets: scalar base + one offset register per access)
+        // The producer and the consumer of a row usually sit in different XCDs, whose L2 caches do not
+        // see each other: the rows travel as agent-scope relaxed atomics (write-through stores, loads
+        // that bypass the local L2), ordered against the progress counter by waiting for the memory
+        // operations themselves - release / acquire FENCES at agent scope write back and invalidate
+        // the whole L2 each time, 80 us per chunk when every wavefront of the chip does it.
+        unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + a.boundaryOff[g]);
+        unsigned long long* bout = reinterpret_cast<unsigned long long*>(a.boundary[s & 1] + a.boundaryOff[g]);
+        auto loadRow = [&](int col) -> uint2 {
+            const unsigned long long v = __hip_atomic_load(bin + (uint32_t)(col * kLanes + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        };
+        int* progOut = a.unitFlags + (size_t)gIdx * nStrips + s;
+        const int* progIn = progOut - 1;
+        const int lastCol = nChunks * 4 - 1;
+        // chunks the strip above must be ahead: the rows of columns up to j + (rows ahead) are fetched
+        constexpr int kLag = 1 + (MIOPAL_STRIP_ROWS_AHEAD + 3) / 4;
+        int avail = fromAbove ? 0 : nChunks;   // chunks of the strip above known to be published
+        bool dead = false;
+        auto waitFor = [&](int need) {
+            // (wave-uniform: every lane reads the same counter)
+            int spins = 0;
+            while (avail < need) {
+                const int v = __hip_atomic_load(const_cast<int*>(progIn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the rows are fetched after the counter)
+                avail = __builtin_amdgcn_readfirstlane(v);
+                if (avail >= need) break;
+                __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
+                if (++spins > kStripSpinCap) avail = kStripPoison;
+            }
+            if (avail >= kStripPoison) dead = true;
+        };
+        waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
+
+        uint32_t best = 0u;
+        // the sweep, compiled for the three kinds of strip (first / inner / last): no selects between
+        // border and row above, no stores from the last strip
+        auto sweep = [&](auto fromAboveC, auto toBelowC) {
+            constexpr bool kFromAbove = decltype(fromAboveC)::value, kToBelow = decltype(toBelowC)::value;
+            uint32_t fl = zero2 - ext2;         // zero of column -1
+            int shift = -ext;                   // fl = zero2 + both(shift); wave-uniform
+            uint32_t H[R], E[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                H[r] = fl;
+                E[r] = zero2;
+            }
+            // row above: column j in hand, the next kRowsAhead columns on their way (the loads go to
+            // memory, past the L2: a microsecond or two, a column takes about one)
+            constexpr int kRowsAhead = MIOPAL_STRIP_ROWS_AHEAD;
+            uint2 bq[kRowsAhead + 1];
+#pragma unroll
+            for (int x = 0; x <= kRowsAhead; ++x) bq[x] = make_uint2(fl, zero2);
+            uint32_t hbPrev = fl;               // H of the row above at column j - 1 (left border: 0)
+            if constexpr (kFromAbove) {
+#pragma unroll
+                for (int x = 0; x < kRowsAhead; ++x) bq[x] = loadRow(min(x, lastCol));
+            }
+            uint2 cur = pack[lane];
+            auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
+                const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
+                return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
+                                                      __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
+            };
+            constexpr int kWant = R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
+            constexpr int kAhead = NB4 > kWant ? kWant : 1;
+            const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
+            uint4 vn[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+            for (int c = 0; c < nChunks && !dead; ++c) {
+                uint2 nxt = {0, 0};
+                if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+                if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
+                uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int j = c * 4 + cc;
+                    const uint4* prow = prowNext;
+                    uint4 v[NB4];
+#pragma unroll
+                    for (int k = 0; k < kAhead; ++k) v[k] = vn[k];
+                    if constexpr (kFromAbove) bq[kRowsAhead] = loadRow(min(j + kRowsAhead, lastCol));
+                    ra = cc < 3 ? ra >> 8 : nxt.x;
+                    rb = cc < 3 ? rb >> 8 : nxt.y;
+                    prowNext = rowOf(ra & 0xffu, rb & 0xffu);
+                    auto score = [&](int r) -> uint32_t {
+                        const uint4 x = v[r >> 2];
+                        const int k = r & 3;
+                        return k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                    };
+                    // the row above at column j - 1, one column to the right; strip 0: the border's 0
+                    uint32_t dsum = (kFromAbove ? hbPrev : fl) + score(0);
+                    fl += ext2;                         // this column's zero
+                    uint32_t fl1 = fl + ext2;           // the next column's
+                    asm volatile("" : "+v"(fl1));
+                    uint32_t f = kFromAbove ? bq[0].y : fl, cm = fl, held = fl;
+#pragma unroll
+                    for (int r4 = 0; r4 < NB4; ++r4) {
+                        if (r4 + kAhead < NB4) v[r4 + kAhead] = prow[r4 + kAhead];
+                        if (r4 == (NB4 > 3 ? NB4 - 3 : 0)) {
+#pragma unroll
+                            for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = r4 * 4 + k;
+                            if (r >= R) continue;
+                            uint32_t dnext = 0;
+                            if (r + 1 < R) dnext = H[r] + score(r + 1);
+                            const uint32_t h = pk_max3_f16(dsum, E[r], f);
+                            if (r & 1) cm = pk_max3_f16(cm, held, h);
+                            else held = h;
+                            const uint32_t hmo = h - openMinusExt2;
+                            E[r] = pk_max3_f16(E[r], hmo, fl1);
+                            f = pk_max3_f16(f, hmo, fl1) - ext2;   // (after the last row: what the strip below starts from)
+                            H[r] = h;
+                            dsum = dnext;
+                        }
+                        asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+                    }
+                    if (R & 1) cm = pk_max3_f16(cm, held, held);
+                    best = pk_max_u16(best, cm - fl);
+                    // (compiled per kind of strip: a run-time branch here costs 27 registers)
+                    if constexpr (kToBelow)
+                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane), ((unsigned long long)f << 32) | H[R - 1],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hbPrev = bq[0].x;
+#pragma unroll
+                    for (int x = 0; x < kRowsAhead; ++x) bq[x] = bq[x + 1];
+                }
+                cur = nxt;
+                shift += 4 * ext;
+                if (shift + 4 * ext > kBiasedMaxShift) {
+                    // rebase (the strip above did the same after this chunk: the rows it wrote from
+                    // the next chunk on are already on the new scale, the one kept in hbPrev is not)
+                    const uint32_t d = both(shift);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        H[r] -= d;
+                        E[r] -= d;
+                    }
+                    hbPrev -= d;
+                    fl -= d;
+                    shift = 0;
+                }
+                if constexpr (kToBelow) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every row store of the chunk has completed
+                    if (lane == 0) __hip_atomic_store(progOut, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+        if (!dead) {
+            if (!fromAbove) sweep(std::false_type{}, std::true_type{});
+            else if (toBelow) sweep(std::true_type{}, std::true_type{});
+            else sweep(std::true_type{}, std::false_type{});
+        }
+        const size_t base = (size_t)g * kGroupTargets;
+        if (dead) {
+            // the strip above never got here: leave the answer to the next rung, tell the strip below
+            if (toBelow && lane == 0) __hip_atomic_store(progOut, kStripPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.overflow) a.overflow[base + lane] = a.overflow[base + kLanes + lane] = 1;
+            continue;
+        }
+        const int lo = (int)(best & 0xffffu), hi = (int)(best >> 16);
+        atomicMax(a.score + base + lane, lo);
+        atomicMax(a.score + base + kLanes + lane, hi);
+        if (a.overflow) {
+            if (lo >= a.biasedLimit) a.overflow[base + lane] = 1;
+            if (hi >= a.biasedLimit) a.overflow[base + kLanes + lane] = 1;
+        }
+    }
+}
+
+template <int R>
+static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + the unit in flight
+    static uint64_t configured = 0;  // one bit per device
+    if (firstUseOnThisDevice(&configured)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
+    }
+    const int nBatches = (a.nGroups + a.batchGroups - 1) / a.batchGroups;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(computeUnits, (int64_t)nBatches * a.nStrips));
+    hipLaunchKernelGGL((interseq_pair_strips_kernel<R>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    return hipGetLastError();
+}
+
+constexpr int kStripsMaxRows = 52;   // taller strips spill (the boundary rows cost 9 registers)
+template <int kLo, int kStep>
+static hipError_t launchPairStripsCase(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    if constexpr (kLo + kStep <= kStripsMaxRows) return launchPairStripsR<kLo + kStep>(a, computeUnits, stream);
+    else return hipErrorInvalidValue;
+}
+template <int kLo>
+static hipError_t launchPairStrips(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    if (a.nStrips < 2 || !a.unitCounter || !a.unitFlags || !a.boundary[0] || !a.boundary[1] || a.batchGroups < 1 ||
+        a.batchGroups > kPairWaves)
+        return hipErrorInvalidValue;
+    switch (rowsPerStrip - kLo) {
+        case 0: return launchPairStripsCase<kLo, 0>(a, computeUnits, stream);
+        case 2: return launchPairStripsCase<kLo, 2>(a, computeUnits, stream);
+        case 4: return launchPairStripsCase<kLo, 4>(a, computeUnits, stream);
+        case 6: return launchPairStripsCase<kLo, 6>(a, computeUnits, stream);
+        case 8: return launchPairStripsCase<kLo, 8>(a, computeUnits, stream);
+        case 10: return launchPairStripsCase<kLo, 10>(a, computeUnits, stream);
+        case 12: return launchPairStripsCase<kLo, 12>(a, computeUnits, stream);
+        case 14: return launchPairStripsCase<kLo, 14>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -292,6 +292,20 @@ GENERAL_HALF = 1 + 32 * 0
 GENERAL_INT16 = 1 + 32 * 1
 
 
+PAIR_STRIPS = 2 + 4            # pair table, one strip after the other (interseq_pair_strips_kernel)
+
+
+@pytest.fixture(params=["strips", "general"])
+def multi_strip(request, monkeypatch):
+    """Both first rungs of a multi-strip Smith-Waterman score search: the pair-table kernel strip by
+    strip (default when the scores fit its guard band) and the general kernel's column-shifted lanes."""
+    if request.param == "general":
+        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
+        return GENERAL_SHIFTED
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")   # (also for searches of few units, where the host prefers the general kernel)
+    return PAIR_STRIPS
+
+
 def shifted_check(capi, query, res, off, matrix, go, ge, expect=GENERAL_SHIFTED, tag=""):
     db = capi.DeviceDatabase(res, off, 24)
     try:
@@ -307,7 +321,7 @@ def shifted_check(capi, query, res, off, matrix, go, ge, expect=GENERAL_SHIFTED,
 
 
 @pytest.mark.parametrize("qlen", [61, 64, 65, 100, 127, 128, 129, 192, 193, 333, 700])
-def test_shifted_lanes_every_kind_of_strip_count(capi, qlen):
+def test_shifted_lanes_every_kind_of_strip_count(capi, qlen, multi_strip):
     rng = np.random.default_rng(4000 + qlen)
     query = _data.random_protein(rng, qlen)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]
@@ -315,11 +329,11 @@ def test_shifted_lanes_every_kind_of_strip_count(capi, qlen):
                              _data.random_protein(rng, int(rng.integers(0, 40)))]) for _ in range(20)]
     seqs += [query[: qlen // 2], query[qlen // 3:], np.zeros(0, dtype=np.uint8)]
     res, off = _oracle.flatten(seqs)
-    shifted_check(capi, query, res, off, B62, 11, 1, tag=f"Q={qlen}")
+    shifted_check(capi, query, res, off, B62, 11, 1, expect=multi_strip, tag=f"Q={qlen}")
 
 
 @pytest.mark.parametrize("go,ge", [(3, 1), (1, 1), (2, 5), (0, 3), (5, 0), (0, 0), (14, 12), (40, 12), (700, 30)])
-def test_shifted_lanes_gap_models(capi, go, ge):
+def test_shifted_lanes_gap_models(capi, go, ge, multi_strip):
     rng = np.random.default_rng(go * 100 + ge + 7)
     query = _data.random_protein(rng, 150)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=300)]
@@ -329,7 +343,7 @@ def test_shifted_lanes_gap_models(capi, go, ge):
     shifted_check(capi, query, res, off, B62, go, ge, expect=None, tag=f"gap {go}/{ge}")
 
 
-def test_shifted_lanes_leave_their_range_and_are_redone(capi):
+def test_shifted_lanes_leave_their_range_and_are_redone(capi, multi_strip):
     # match 100, ext 2, targets of at most ~420 residues: exact below 0x7C00 - 0x1000 - 2 (420 + 8) or so;
     # copies of k query residues score 100 k on both sides of that (k = 267)
     rng = np.random.default_rng(31)
@@ -341,12 +355,13 @@ def test_shifted_lanes_leave_their_range_and_are_redone(capi):
         seqs.append(np.concatenate([_data.random_protein(rng, 30), query[:k], _data.random_protein(rng, 20)]))
         seqs.append(np.concatenate([query[300 - k:], _data.random_protein(rng, 50)]))
     res, off = _oracle.flatten(seqs)
-    routed = shifted_check(capi, query, res, off, m, 5, 2, tag="match 100")
-    limit = 0x7C00 - 0x1000 - 2 * (max(len(s) for s in seqs) + 64)
+    routed = shifted_check(capi, query, res, off, m, 5, 2, expect=multi_strip, tag="match 100")
+    # (the strips kernel rebases its column shift: exact below 25600 whatever the targets' lengths)
+    limit = 25600 if multi_strip == PAIR_STRIPS else 0x7C00 - 0x1000 - 2 * (max(len(s) for s in seqs) + 64)
     assert 2 * sum(1 for k in ks if 100 * k >= limit) <= routed[3] <= 2 * sum(1 for k in ks if 100 * k >= limit - 2000)
 
 
-def test_shifted_lanes_large_steps_lower_the_limit(capi):
+def test_shifted_lanes_large_steps_lower_the_limit(capi, multi_strip):
     # match + ext = 3000: a finite pattern could step over 0x7C00..0x7FFF; the limit gives the excess away
     rng = np.random.default_rng(32)
     m = scaled_identity(24, 2900, -900)
@@ -355,10 +370,10 @@ def test_shifted_lanes_large_steps_lower_the_limit(capi):
     seqs += [np.concatenate([_data.random_protein(rng, 7), query[:k], _data.random_protein(rng, 3)])
              for k in (130, 40, 12, 11, 10, 9, 8, 7, 6, 5, 4)]
     res, off = _oracle.flatten(seqs)
-    shifted_check(capi, query, res, off, m, 1000, 100, tag="match 2900")
+    shifted_check(capi, query, res, off, m, 1000, 100, expect=multi_strip, tag="match 2900")
 
 
-def test_shifted_lanes_negative_scores_are_biased(capi):
+def test_shifted_lanes_negative_scores_are_biased(capi, multi_strip):
     # mismatch -900 at ext 1: profile entries are s + ext + 899 >= 0, the column term takes the 899 back
     rng = np.random.default_rng(33)
     m = scaled_identity(24, 60, -900)
@@ -366,29 +381,30 @@ def test_shifted_lanes_negative_scores_are_biased(capi):
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 300, size=300)]
     seqs += [_data.mutate(rng, query, f) for f in (0.0, 0.01, 0.02, 0.05, 0.1)]
     res, off = _oracle.flatten(seqs)
-    shifted_check(capi, query, res, off, m, 20, 1, tag="mismatch -900")
+    shifted_check(capi, query, res, off, m, 20, 1, expect=multi_strip, tag="mismatch -900")
     # beyond the room below zero: another rung, same scores
     m = scaled_identity(24, 60, -3000)
     routed = shifted_check(capi, query, res, off, m, 20, 1, expect=None, tag="mismatch -3000")
     assert routed[1] in (GENERAL_HALF, GENERAL_INT16)
 
 
-def test_shifted_lanes_are_not_used_when_the_columns_eat_the_range(capi):
-    # ext 200 x a few hundred columns leaves nothing above zero: the half-float / int16 rungs run
+def test_shifted_lanes_are_not_used_when_the_columns_eat_the_range(capi, multi_strip):
+    # ext 200 x a few hundred columns leaves nothing above zero for the general kernel's shifted lanes
+    # (the half-float / int16 rungs run); the strips kernel rebases its shift and takes it
     rng = np.random.default_rng(34)
     query = _data.random_protein(rng, 100)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(300, 400, size=330)]
     seqs[3] = np.concatenate([seqs[3][:200], _data.mutate(rng, query, 0.05), seqs[3][200:250]])
     res, off = _oracle.flatten(seqs)
     routed = shifted_check(capi, query, res, off, B62, 210, 200, expect=None, tag="ext 200")
-    assert routed[1] in (GENERAL_HALF, GENERAL_INT16)
+    assert routed[1] == PAIR_STRIPS if multi_strip == PAIR_STRIPS else routed[1] in (GENERAL_HALF, GENERAL_INT16)
     # at ext 1 the same targets fit, and so do much longer ones (Smith-Waterman searches see long
     # targets through windows of a few query lengths)
-    shifted_check(capi, query, res, off, B62, 11, 1, tag="ext 1")
+    shifted_check(capi, query, res, off, B62, 11, 1, expect=multi_strip, tag="ext 1")
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1500, 2000, size=130)]
     seqs[3] = np.concatenate([seqs[3][:900], _data.mutate(rng, query, 0.05), seqs[3][900:1000]])
     res, off = _oracle.flatten(seqs)
-    shifted_check(capi, query, res, off, B62, 14, 12, tag="ext 12, long targets")
+    shifted_check(capi, query, res, off, B62, 14, 12, expect=multi_strip, tag="ext 12, long targets")
 
 
 def test_switch_restores_the_half_float_rung_of_the_general_kernel(capi, monkeypatch):
@@ -396,4 +412,100 @@ def test_switch_restores_the_half_float_rung_of_the_general_kernel(capi, monkeyp
     query = _data.random_protein(rng, 150)
     res, off = _data.random_db(rng, rng.integers(20, 300, size=500))
     monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
+    monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     shifted_check(capi, query, res, off, B62, 3, 1, expect=GENERAL_HALF, tag="switch")
+
+
+# --- the strips kernel's own corners ---
+def test_strips_many_rebases_and_long_ragged_groups(capi, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    # ext 400: the column shift is rebased every other chunk, in every strip at the same chunks (the rows
+    # handed from strip to strip must mean the same on both sides); log-normal lengths: groups of very
+    # different lengths in one batch, wavefronts that wait at the unit's barrier
+    rng = np.random.default_rng(61)
+    query = _data.random_protein(rng, 170)
+    lengths = np.clip(rng.lognormal(5.5, 0.8, size=3000).astype(int), 1, 4000)
+    seqs = [_data.random_protein(rng, int(n)) for n in lengths]
+    seqs += [np.concatenate([_data.random_protein(rng, 600), _data.mutate(rng, query, 0.1), _data.random_protein(rng, 40)])
+             for _ in range(10)]
+    res, off = _oracle.flatten(seqs)
+    shifted_check(capi, query, res, off, B62, 500, 400, expect=PAIR_STRIPS, tag="ext 400")
+    shifted_check(capi, query, res, off, B62, 11, 1, expect=PAIR_STRIPS, tag="ext 1")
+
+
+def test_strips_overflow_crosses_strip_boundaries(capi, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    # match 500 on a 200-residue query: copies of 52 residues and more leave the exact range (25600), the
+    # pattern that turns inf / NaN in one strip travels down the boundary rows; every such lane is redone
+    rng = np.random.default_rng(62)
+    m = scaled_identity(24, 500, -300)
+    query = _data.random_protein(rng, 200)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 300, size=400)]
+    for k in (200, 120, 60, 53, 52, 51, 50, 49, 30):
+        for at in (0, 37, 100):   # the copy starts in different strips
+            seqs.append(np.concatenate([_data.random_protein(rng, 11), query[at:at + k], _data.random_protein(rng, 5)]))
+    res, off = _oracle.flatten(seqs)
+    routed = shifted_check(capi, query, res, off, m, 700, 100, expect=PAIR_STRIPS, tag="match 500")
+    assert routed[3] >= 9
+
+
+@pytest.mark.parametrize("A,qlen", [(4, 130), (12, 333), (32, 64), (32, 100), (32, 50)])
+def test_strips_other_alphabets(capi, A, qlen, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    # the pair table of a 33-symbol alphabet holds 36 rows: 64 rows are two strips of 32, 100 rows three
+    # of 34; 50 rows would be two strips of 26, below the kernel's 32, and stay on the general kernel
+    rng = np.random.default_rng(A * 1000 + qlen)
+    matrix = rng.integers(-6, 8, size=(A, A)).astype(np.int32)
+    matrix[np.arange(A), np.arange(A)] = rng.integers(3, 12, size=A)
+    seqs = [rng.integers(0, A, size=int(n)).astype(np.uint8) for n in rng.integers(1, 400, size=500)]
+    q = rng.integers(0, A, size=qlen).astype(np.uint8)
+    seqs += [np.concatenate([seqs[k][:50], q, seqs[k][:30]]) for k in range(5)]
+    res, off = _oracle.flatten(seqs)
+    db = capi.DeviceDatabase(res, off, A)
+    try:
+        got = db.search(q, matrix.ravel(), 5, 2, "score", "sw")["score"]
+        routed = capi.DeviceDatabase.last_routing()
+    finally:
+        db.close()
+    want = _oracle.search(q, res, off, matrix.ravel(), 5, 2, "score", "sw")["score"]
+    np.testing.assert_array_equal(got, want)
+    assert (routed[1] == PAIR_STRIPS) == ((A, qlen) != (32, 50))
+
+
+def test_strips_few_groups_long_query(capi, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    # 40 strips over 3 batches: the units of a batch run side by side in different workgroups, each
+    # wavefront two chunks behind the one above it
+    rng = np.random.default_rng(63)
+    query = _data.random_protein(rng, 2000)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1500, 2500, size=4000)]
+    seqs[7] = np.concatenate([seqs[7][:300], _data.mutate(rng, query, 0.3), seqs[7][300:400]])
+    res, off = _oracle.flatten(seqs)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        got = db.search(query, B62, 11, 1, "score", "sw")["score"]
+        assert capi.DeviceDatabase.last_routing()[1] == PAIR_STRIPS
+    finally:
+        db.close()
+    import _cpu_baseline
+    cpu = _cpu_baseline.CpuDatabase(res, off)
+    want = cpu.search_sw(query, B62, 11, 1, 8)
+    cpu.close()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_strips_routing_by_size(capi):
+    # few (group, strip) units, or a longest group that is long against the whole launch: the general
+    # kernel; many units of groups that are short against the launch: the strips kernel
+    rng = np.random.default_rng(64)
+    res, off = _data.random_db(rng, np.full(100_000, 100))
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for qlen, lo, hi, want in ((100, 0, 100_000, 1), (100, 0, 3000, 1), (600, 0, 100_000, PAIR_STRIPS), (900, 0, 3000, 1)):
+            q = _data.random_protein(rng, qlen)
+            got = db.search(q, B62, 11, 1, "score", "sw", lo, hi)["score"]
+            assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (qlen, hi)
+            ref = _oracle.search(q, res[:off[200]], off[:201], B62, 11, 1, "score", "sw")["score"]
+            np.testing.assert_array_equal(got[:200], ref)
+    finally:
+        db.close()

@@ -206,6 +206,7 @@ def test_sw_lane_width_ladder(capi, monkeypatch, first_rung):
     # (round 2) holds the 480-residue query's hits itself and only hands the 6500-residue ones on.
     if first_rung == "half":
         monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
+        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     rng = np.random.default_rng(14)
     q = _data.random_protein(rng, 6500)
     short = q[:480].copy()
@@ -522,6 +523,7 @@ def test_segmented_view_with_lanes_leaving_the_half_float_range(capi, monkeypatc
     column-shifted first rung of round 2 (ArithSwU16) holds these scores itself: nothing is redone."""
     if first_rung == "half":
         monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
+        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     rng = np.random.default_rng(5)
     lengths = np.clip(rng.lognormal(5.3, 0.5, size=20_000), 10, 1500).astype(np.int64)
     lengths[:30] = rng.integers(4000, 7000, size=30)

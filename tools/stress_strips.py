@@ -1,0 +1,41 @@
+"""Repeats multi-strip Smith-Waterman score searches on the pair-table strips kernel and compares every
+run with the general kernel's answer: the rows handed from strip to strip cross XCDs on relaxed
+agent-scope atomics ordered by hand (interseq_impl.h), a lost ordering would show as a wrong score in
+some run. Usage: stress_strips.py [iterations]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _data
+from pyopal_amd import _capi
+from pyopal_amd.matrices import ScoringMatrix
+
+m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+os.environ["MIOPAL_PAIR_STRIPS"] = "1"   # also where the host would prefer the general kernel (few units)
+rng = np.random.default_rng(17)
+cases = [
+    ("100k x 2000, Q=2000", np.full(100_000, 2000), 2000, max(1, ITER // 4)),
+    ("1M x 300, Q=300", np.full(1_000_000, 300), 300, ITER),
+    ("log-normal 500k, Q=150", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER),
+    ("30k x 300, Q=640 (few batches, 13 strips)", np.full(30_000, 300), 640, ITER),
+]
+for name, lengths, Q, iters in cases:
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, Q)
+    db = _capi.DeviceDatabase(res, off, 24)
+    os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
+    want = db.search(q, m, 3, 1, "score", "sw")["score"]
+    assert (_capi.DeviceDatabase.last_routing()[1] & 15) == 1
+    os.environ.pop("MIOPAL_NO_PAIR_STRIPS")
+    bad = 0
+    t0 = time.perf_counter()
+    for k in range(iters):
+        got = db.search(q, m, 3, 1, "score", "sw")["score"]
+        assert _capi.DeviceDatabase.last_routing()[1] == 6
+        if not np.array_equal(got, want):
+            bad += 1
+            print(f"  {name}: run {k}: {int((got != want).sum())} scores differ", flush=True)
+    print(f"{name}: {iters} runs, {bad} with differences, {(time.perf_counter() - t0) / iters * 1e3:.2f} ms per search", flush=True)
+    db.close()
+    assert bad == 0
