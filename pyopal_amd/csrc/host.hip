@@ -1650,7 +1650,7 @@ struct Search {
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
                 // groups of similar length: every SIMD takes the same share of them (interseq_impl.h)
                 {
-                    const int blocks = std::max(1, std::min(pairUnits, (ia.nGroups + 11) / 12));
+                    const int blocks = std::max(1, std::min(pairUnits, ia.nGroups));
                     const int longest = view->groupChunksHost[firstGroup];
                     const int shortest = view->groupChunksHost[view->nGroups - 1];
                     const char* tt = getenv("MIOPAL_TAIL_THROTTLE");

@@ -1031,7 +1031,10 @@ static hipError_t launchPairR(const InterseqArgs& a, int computeUnits, hipStream
             return e;
         }
     }
-    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
+    // (every CU takes part even when the groups are fewer than its wavefronts: the first round hands
+    // out group g to wavefront tier g / blocks of workgroup g % blocks, and a wavefront alone on its
+    // SIMD sweeps its group three times faster than one of three)
+    const int blocks = std::max(1, std::min(computeUnits, a.nGroups));
     hipLaunchKernelGGL((interseq_pair_kernel<R, Arith>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
@@ -1330,7 +1333,10 @@ static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hip
             return e;
         }
     }
-    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kPairWaves - 1) / kPairWaves));
+    // (every CU takes part even when the groups are fewer than its wavefronts: the first round hands
+    // out group g to wavefront tier g / blocks of workgroup g % blocks, and a wavefront alone on its
+    // SIMD sweeps its group three times faster than one of three)
+    const int blocks = std::max(1, std::min(computeUnits, a.nGroups));
     hipLaunchKernelGGL((interseq_pair_biased_kernel<R, LOC>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
@@ -1914,7 +1920,7 @@ static hipError_t launchPairGlobalR(const InterseqArgs& a, int computeUnits, hip
         }
     }
     constexpr int kGlobalWaves = globalWaves(R);
-    const int blocks = std::max(1, std::min(computeUnits, (a.nGroups + kGlobalWaves - 1) / kGlobalWaves));
+    const int blocks = std::max(1, std::min(computeUnits, a.nGroups));   // (see launchPairBiasedR)
     hipLaunchKernelGGL((interseq_pair_global_kernel<R>), dim3(blocks), dim3(kGlobalWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
