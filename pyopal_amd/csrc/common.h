@@ -49,6 +49,10 @@ struct InterseqArgs {
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
+    unsigned long long* stripKeys;   // strips kernel with end locations: (score, column, row) keys, view order, zeroed
+    int* stripAbort;           // strips kernel: lanes flagged so far (first flags only); at stripAbortAt the launch gives up:
+    int stripAbortAt;          //   the view is redone by the next rung anyway (it adds the same to *stripGaveUp)
+    int* stripGaveUp;          //   = the overflow counter the host reads after the scatter
     int batchGroups;           // strips kernel: groups a workgroup sweeps side by side (1..12; fewer when the groups are few)
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
@@ -179,6 +183,7 @@ enum PairFlavour : int {
     kPairSwStrips = 4      // Smith-Waterman scores of several strips on biased halves (units of (batch, strip))
 };
 // limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
+constexpr int kPairStripsMaxRows = 52, kPairStripsMaxRowsLoc = 48;   // tallest strips of the multi-strip pair-table kernel
 constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
 constexpr int kBiasedMaxMagnitude = 1024;  // |score|, open - ext, ext - open
 constexpr int kBiasedMaxExt = 512;
@@ -197,6 +202,10 @@ hipError_t launchInterseqPairSwBiasedC(const InterseqArgs& a, int rows, int comp
 hipError_t launchInterseqPairSwBiasedD(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwStripsLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairSwStripsLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+// (score, column, row) keys of the strips kernel -> view-order scores and end locations
+hipError_t launchDecodeStripKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ, hipStream_t stream);
 hipError_t launchInterseqPairGlobalA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalC(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

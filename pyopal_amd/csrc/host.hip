@@ -147,7 +147,7 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kUnitState, kUnitPartial, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kUnitState, kUnitPartial, kStripKeys, kSlots
 };
 
 struct Workspace {
@@ -1050,6 +1050,7 @@ struct Search {
     int64_t balancedChunks = 0;
     bool globalPairRefused = false;   // the pair-table launch for NW / HW / OV failed on this device
     bool pairStripsRefused = false;   // the same for the multi-strip Smith-Waterman kernel
+    bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
 
     uint8_t* d_query = nullptr;
     int32_t* d_matrix = nullptr;
@@ -1315,14 +1316,19 @@ struct Search {
             const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
             const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
             const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
-            const bool band = up <= kBiasedMaxStepUp && down <= kBiasedMaxMagnitude && 5 * (int64_t)ext <= kLocMaxShift &&
-                              minScore > kBiasedPad;
+            // (with end locations every value is scaled by 2^bits: the row inside a strip of 32 .. 48 rows)
+            const bool wantEnds = searchType != OPAL_SEARCH_SCORE;
+            auto band = [&](int rowsP) {
+                const int sbits = wantEnds ? locRowBitsHost(rowsP) : 0;
+                return (up << sbits) <= kBiasedMaxStepUp && (down << sbits) <= (wantEnds ? kLocGuardBand : kBiasedMaxMagnitude) &&
+                       5 * ((int64_t)ext << sbits) <= kLocMaxShift && minScore > kBiasedPad;
+            };
             const int single = std::max(2, (Q + 1) / 2 * 2);
             const bool oneStrip = Q <= kLanes && interseqPairFits(single, A + 1);
-            int maxRows = 52;
+            int maxRows = wantEnds ? kPairStripsMaxRowsLoc : kPairStripsMaxRows;
             while (maxRows >= 32 && !interseqPairFits(maxRows, A + 1)) maxRows -= 2;
-            if (mode == OPAL_MODE_SW && searchType == OPAL_SEARCH_SCORE && useHalf && band && !oneStrip && maxRows >= 32 &&
-                !pairStripsRefused && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
+            if (mode == OPAL_MODE_SW && Q < (1 << 20) && useHalf && !oneStrip && maxRows >= 32 &&
+                !pairStripsRefused && !(wantEnds && stripsEndsDeclined) && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
                 !getenv("MIOPAL_NO_PAIR_STRIPS") && !getenv("MIOPAL_STRIPS")) {
                 const int ns = std::max(2, (Q + maxRows - 1) / maxRows);
                 const int rowsP = ((Q + ns - 1) / ns + 1) / 2 * 2;
@@ -1342,7 +1348,7 @@ struct Search {
                 const int64_t balanced = totalChunks * ns / ((int64_t)db->computeUnits * 12);
                 const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= balanced;
                 const bool enough = ((ns >= 16 || 2 * units >= 5 * (int64_t)db->computeUnits) && hidden) || getenv("MIOPAL_PAIR_STRIPS");
-                if (enough && rowsP >= 32 && rowsP <= maxRows && (int64_t)(ns - 1) * rowsP < Q && ns <= 4096) {
+                if (enough && rowsP >= 32 && rowsP <= maxRows && band(rowsP) && (int64_t)(ns - 1) * rowsP < Q && ns <= 4096) {
                     stripRows = rowsP;
                     nStrips = ns;
                     waves = 1;   // (strips of a group in turn, each in its own unit)
@@ -1395,7 +1401,7 @@ struct Search {
             // the NaN patterns, a step down (score + ext, open - ext) within the room below zero.
             // With end locations every value is scaled by 2^bits (row keys in the low bits).
             const int pairRows = std::max(2, (Q + 1) / 2 * 2);
-            const int bits = locate ? locRowBitsHost(pairRows) : 0;
+            const int bits = locate ? locRowBitsHost(pairStrips ? stripRows : pairRows) : 0;
             const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
             const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
             // (A step up of more than 0x0400 could carry a finite half past the NaN patterns, 0x7C00 to
@@ -1594,13 +1600,25 @@ struct Search {
                 // unit counter + chunks published per (group, strip); scores and flags start from zero
                 // (a group's answer is the maximum over its strips' units)
                 void* us;
-                const size_t ints = (size_t)ia.nGroups * nStrips + 1;
+                const size_t ints = (size_t)ia.nGroups * nStrips + 2;
                 RC_TRY(ws->get(kUnitState, ints * sizeof(int), &us));
                 HIP_TRY(hipMemsetAsync(us, 0, ints * sizeof(int), stream));
+                if (mayOverflow) {
+                    // more flagged lanes than are redone one by one: the launch stops, the view takes the next rung
+                    ia.stripAbort = (int*)us + ints - 1;
+                    ia.stripAbortAt = 2 * kMaxDirectRecompute;
+                    ia.stripGaveUp = (int*)ct;
+                }
                 HIP_TRY(hipMemsetAsync(vs, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
                 HIP_TRY(hipMemsetAsync(vo, 0, (size_t)view->nGroups * kGroupTargets, stream));
                 ia.unitCounter = (int*)us;
                 ia.unitFlags = (int*)us + 1;
+                if (locate) {
+                    void* sk;
+                    RC_TRY(ws->get(kStripKeys, (size_t)view->nGroups * kGroupTargets * sizeof(unsigned long long), &sk));
+                    HIP_TRY(hipMemsetAsync(sk, 0, (size_t)view->nGroups * kGroupTargets * sizeof(unsigned long long), stream));
+                    ia.stripKeys = (unsigned long long*)sk;
+                }
             } else if ((nStrips + waves - 1) / waves > 1 && !locate && !usePair && !globalPair && wantUnits) {
                 void *us, *up;
                 const size_t ints = (size_t)ia.nGroups + 1;
@@ -1627,7 +1645,40 @@ struct Search {
                 // few (group, strip) units: fewer groups per workgroup, so that every CU gets a unit and a
                 // wavefront shares its SIMD with fewer others
                 ia.batchGroups = (int)std::max<int64_t>(1, std::min<int64_t>(12, (int64_t)ia.nGroups * nStrips / std::max(1, pairUnits)));
-                const hipError_t pe = launchInterseqPair(ia, rows, kPairSwStrips, pairUnits, stream, false);
+                hipError_t pe = hipSuccess;
+                // (random pairs only get there in the linear regime of the scoring system, and then score
+                // about half a unit per aligned residue: nothing to probe for under ~500 residues)
+                if (locate && mayOverflow && std::min(Q, view->maxPackedLen) >= 512 && !getenv("MIOPAL_PAIR_STRIPS")) {
+                    // With end locations a lane is exact below 384 (768 for strips of 32 rows). Scores of
+                    // long queries against long targets under cheap gaps are in the thousands - every lane
+                    // would be redone, and a launch that gives up half-way has cost half its time. The
+                    // twelve longest groups (the highest scores) go through the scores-only kernel first:
+                    // 1536 targets, a unit's time; when half of them are beyond the range the general
+                    // kernel takes the search.
+                    InterseqArgs probe = ia;
+                    probe.nGroups = std::min(12, ia.nGroups);
+                    probe.batchGroups = 1;
+                    probe.overflow = nullptr;
+                    probe.stripKeys = nullptr;
+                    probe.stripAbort = nullptr;
+                    pe = launchInterseqPair(probe, rows, kPairSwStrips, pairUnits, stream, false);
+                    if (pe == hipSuccess) {
+                        const int lanes = probe.nGroups * kGroupTargets;
+                        std::vector<int32_t> seen((size_t)lanes);
+                        RC_TRY(ws->stageDownload(seen.data(), ia.score + (size_t)firstGroup * kGroupTargets, (size_t)lanes * sizeof(int32_t)));
+                        RC_TRY(ws->finishDownloads());
+                        int beyond = 0;
+                        for (int32_t v : seen) beyond += v >= biasedLimit;
+                        if (2 * beyond >= lanes) {
+                            stripsEndsDeclined = true;
+                            return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
+                        }
+                        // (the probe's units and scores are wiped: the real launch starts from zero)
+                        HIP_TRY(hipMemsetAsync(ia.unitCounter, 0, ((size_t)ia.nGroups * nStrips + 2) * sizeof(int), stream));
+                        HIP_TRY(hipMemsetAsync(ia.score, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
+                    }
+                }
+                if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, kPairSwStrips, pairUnits, stream, locate);
                 if (pe != hipSuccess) {
                     // (e.g. the runtime refuses 150 KB of dynamic LDS: start over on the general kernel)
                     (void)hipGetLastError();
@@ -1637,6 +1688,9 @@ struct Search {
                                 hipGetErrorString(pe));
                     return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
                 }
+                // (score, column, row) keys merged over the strips -> view-order scores and end locations
+                if (locate)
+                    HIP_TRY(launchDecodeStripKeys(ia.stripKeys, view->nGroups * kGroupTargets, ia.score, ia.endI, ia.endJ, stream));
             } else if (usePair || globalPair) {
                 void* wc;
                 RC_TRY(ws->get(kWorkCounter, sizeof(int), &wc));

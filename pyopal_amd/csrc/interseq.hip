@@ -38,7 +38,7 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols) {
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream, bool locate) {
     if (a.nGroups <= 0) return hipSuccess;
-    if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased) return hipErrorInvalidValue;
+    if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased && flavour != kPairSwStrips) return hipErrorInvalidValue;
     if (a.nStrips != 1 && flavour != kPairSwStrips) return hipErrorInvalidValue;
     switch (flavour) {
         case kPairGlobalBiased:
@@ -62,7 +62,12 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
             if (rowsPerStrip < 50) return launchInterseqPairSwBiasedC(a, rowsPerStrip, computeUnits, stream);
             return launchInterseqPairSwBiasedD(a, rowsPerStrip, computeUnits, stream);
         case kPairSwStrips:
-            if (rowsPerStrip < 32 || rowsPerStrip > 52 || (rowsPerStrip & 1)) return hipErrorInvalidValue;
+            if (rowsPerStrip < 32 || rowsPerStrip > (locate ? kPairStripsMaxRowsLoc : kPairStripsMaxRows) || (rowsPerStrip & 1))
+                return hipErrorInvalidValue;
+            if (locate) {
+                if (rowsPerStrip < 48) return launchInterseqPairSwStripsLocA(a, rowsPerStrip, computeUnits, stream);
+                return launchInterseqPairSwStripsLocB(a, rowsPerStrip, computeUnits, stream);
+            }
             if (rowsPerStrip < 48) return launchInterseqPairSwStripsA(a, rowsPerStrip, computeUnits, stream);
             return launchInterseqPairSwStripsB(a, rowsPerStrip, computeUnits, stream);
         case kPairSwHalf: return launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream);

@@ -1386,17 +1386,21 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 constexpr int kStripPoison = 1 << 30;
 constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
 
-template <int R>
+template <int R, bool LOC>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kernel(InterseqArgs a) {
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
     constexpr int NB4 = (R + 3) / 4;
+    // end locations (LOC): values scaled by 2^kBits, the row inside the strip in the low bits of what
+    // the column maximum folds - the one-strip kernel's scheme, per strip
+    constexpr int kBits = LOC ? locRowBits(R) : 0;
+    constexpr int kRowMask = (1 << kBits) - 1;
     extern __shared__ uint4 pairs[];
 
     const int lane = threadIdx.x & 63;
     const int nSym = a.nSymbols;
-    const int ext = a.gapExt;
-    const uint32_t ext2 = both(ext), openMinusExt2 = both(a.gapOpen - ext);
-    const uint32_t zero2 = both(kBiasedZero);
+    const int ext = a.gapExt << kBits;   // pattern units
+    const uint32_t ext2 = both(ext), openMinusExt2 = both((a.gapOpen << kBits) - ext);
+    const uint32_t zero2 = both(LOC ? kLocZero : kBiasedZero);
     const int nStrips = a.nStrips;
     const int perBatch = a.batchGroups;   // 12, or fewer when the groups are few (more CUs, faster wavefronts)
     const int nBatches = (a.nGroups + perBatch - 1) / perBatch;
@@ -1405,7 +1409,17 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
     int tableStrip = -1;
 
     for (;;) {
-        if (threadIdx.x == 0) ctl[0] = atomicAdd(a.unitCounter, 1);
+        if (threadIdx.x == 0) {
+            int next = atomicAdd(a.unitCounter, 1);
+            // Too many lanes have left the exact range: the host will redo the whole view on the next
+            // rung whatever this launch still computes (end locations of long queries against long
+            // targets under cheap gaps: scores in the thousands, a range of 384) - stop here.
+            if (a.stripAbort && __hip_atomic_load(a.stripAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.stripAbortAt) {
+                if (next < nBatches * nStrips) atomicAdd(a.stripGaveUp, a.stripAbortAt);
+                next = INT32_MAX;
+            }
+            ctl[0] = next;
+        }
         __syncthreads();   // (and: every wavefront has left the table of the unit before)
         const int u = __builtin_amdgcn_readfirstlane(ctl[0]);
         if (u >= nBatches * nStrips) break;
@@ -1422,7 +1436,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
                 const int row = idx / R, r = idx - row * R;
                 const int tA = row / nSym, tB = row - tA * nSym;
-                const int sA = gp[tA * a.qPad + r] + ext, sB = gp[tB * a.qPad + r] + ext;
+                constexpr int kPadPattern = LOC ? -kLocGuard : kBiasedPadScore;
+                const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
+                const int sA = (vA == kBiasedPadScore ? kPadPattern : vA << kBits) + ext;
+                const int sB = (vB == kBiasedPadScore ? kPadPattern : vB << kBits) + ext;
                 pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
             }
             tableStrip = s;
@@ -1467,12 +1484,16 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 if (avail >= need) break;
                 __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
                 if (++spins > kStripSpinCap) avail = kStripPoison;
+                // (the unit above may never be taken once the launch has given up)
+                if (a.stripAbort && __hip_atomic_load(a.stripAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.stripAbortAt)
+                    avail = kStripPoison;
             }
             if (avail >= kStripPoison) dead = true;
         };
         waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
 
-        uint32_t best = 0u;
+        uint32_t best = 0u;                 // true values (LOC: keys), integer order
+        int colA = -1, colB = -1;           // LOC: column of the first maximum of each half in this strip
         // the sweep, compiled for the three kinds of strip (first / inner / last): no selects between
         // border and row above, no stores from the last strip
         auto sweep = [&](auto fromAboveC, auto toBelowC) {
@@ -1549,8 +1570,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                             uint32_t dnext = 0;
                             if (r + 1 < R) dnext = H[r] + score(r + 1);
                             const uint32_t h = pk_max3_f16(dsum, E[r], f);
-                            if (r & 1) cm = pk_max3_f16(cm, held, h);
-                            else held = h;
+                            const uint32_t hk = LOC ? h + both(kRowMask - r) : h;
+                            if (r & 1) cm = pk_max3_f16(cm, held, hk);
+                            else held = hk;
                             const uint32_t hmo = h - openMinusExt2;
                             E[r] = pk_max3_f16(E[r], hmo, fl1);
                             f = pk_max3_f16(f, hmo, fl1) - ext2;   // (after the last row: what the strip below starts from)
@@ -1560,7 +1582,21 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                         asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
                     }
                     if (R & 1) cm = pk_max3_f16(cm, held, held);
-                    best = pk_max_u16(best, cm - fl);
+                    if constexpr (LOC) {
+                        // strictly greater scores only: compare against best with its row bits all set
+                        const uint32_t cand = cm - fl, thr = best | both(kRowMask);
+                        const uint32_t ch = pk_max_u16(thr, cand) ^ thr;   // nonzero half: new maximum
+                        if (ch & 0xffffu) {
+                            best = (best & 0xffff0000u) | (cand & 0xffffu);
+                            colA = j;
+                        }
+                        if (ch >> 16) {
+                            best = (best & 0xffffu) | (cand & 0xffff0000u);
+                            colB = j;
+                        }
+                    } else {
+                        best = pk_max_u16(best, cm - fl);
+                    }
                     // (compiled per kind of strip: a run-time branch here costs 27 registers)
                     if constexpr (kToBelow)
                         __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane), ((unsigned long long)f << 32) | H[R - 1],
@@ -1602,22 +1638,41 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             if (a.overflow) a.overflow[base + lane] = a.overflow[base + kLanes + lane] = 1;
             continue;
         }
-        const int lo = (int)(best & 0xffffu), hi = (int)(best >> 16);
-        atomicMax(a.score + base + lane, lo);
-        atomicMax(a.score + base + kLanes + lane, hi);
+        const int lo = (int)(best & 0xffffu) >> kBits, hi = (int)(best >> 16) >> kBits;
+        if constexpr (LOC) {
+            // first maximum in column-major order over the strips: highest score, then smallest column,
+            // then smallest row, as one 64-bit key (a strip without a positive cell contributes nothing)
+            auto key = [&](int score, int col, uint32_t half) -> unsigned long long {
+                const int row = s * R + (kRowMask - (int)(half & kRowMask));
+                return ((unsigned long long)(unsigned)score << 40) | ((unsigned long long)(0xFFFFFu - (unsigned)col) << 20) |
+                       (unsigned long long)(0xFFFFFu - (unsigned)row);
+            };
+            if (colA >= 0) atomicMax(a.stripKeys + base + lane, key(lo, colA, best));
+            if (colB >= 0) atomicMax(a.stripKeys + base + kLanes + lane, key(hi, colB, best >> 16));
+        } else {
+            atomicMax(a.score + base + lane, lo);
+            atomicMax(a.score + base + kLanes + lane, hi);
+        }
         if (a.overflow) {
-            if (lo >= a.biasedLimit) a.overflow[base + lane] = 1;
-            if (hi >= a.biasedLimit) a.overflow[base + kLanes + lane] = 1;
+            // (first flags only are counted: a lane that left the range in this strip usually does in the next)
+            const bool fa = lo >= a.biasedLimit && a.overflow[base + lane] == 0;
+            const bool fb = hi >= a.biasedLimit && a.overflow[base + kLanes + lane] == 0;
+            if (fa) a.overflow[base + lane] = 1;
+            if (fb) a.overflow[base + kLanes + lane] = 1;
+            if (a.stripAbort) {
+                const int fresh = __popcll(__builtin_amdgcn_ballot_w64(fa)) + __popcll(__builtin_amdgcn_ballot_w64(fb));
+                if (fresh > 0 && lane == 0) atomicAdd(a.stripAbort, fresh);
+            }
         }
     }
 }
 
-template <int R>
+template <int R, bool LOC>
 static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
     const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + the unit in flight
     static uint64_t configured = 0;  // one bit per device
     if (firstUseOnThisDevice(&configured)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R, LOC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             int dev = 0;
@@ -1628,30 +1683,33 @@ static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hip
     }
     const int nBatches = (a.nGroups + a.batchGroups - 1) / a.batchGroups;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(computeUnits, (int64_t)nBatches * a.nStrips));
-    hipLaunchKernelGGL((interseq_pair_strips_kernel<R>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    hipLaunchKernelGGL((interseq_pair_strips_kernel<R, LOC>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
 
-constexpr int kStripsMaxRows = 52;   // taller strips spill (the boundary rows cost 9 registers)
-template <int kLo, int kStep>
+constexpr int kStripsMaxRows = 52;      // taller strips spill (the boundary rows cost 9 registers)
+constexpr int kStripsMaxRowsLoc = 48;   // with end locations
+static_assert(kStripsMaxRows == kPairStripsMaxRows && kStripsMaxRowsLoc == kPairStripsMaxRowsLoc, "common.h mirrors these");
+template <int kLo, int kStep, bool LOC>
 static hipError_t launchPairStripsCase(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    if constexpr (kLo + kStep <= kStripsMaxRows) return launchPairStripsR<kLo + kStep>(a, computeUnits, stream);
+    if constexpr (kLo + kStep <= (LOC ? kStripsMaxRowsLoc : kStripsMaxRows))
+        return launchPairStripsR<kLo + kStep, LOC>(a, computeUnits, stream);
     else return hipErrorInvalidValue;
 }
-template <int kLo>
+template <int kLo, bool LOC>
 static hipError_t launchPairStrips(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
     if (a.nStrips < 2 || !a.unitCounter || !a.unitFlags || !a.boundary[0] || !a.boundary[1] || a.batchGroups < 1 ||
-        a.batchGroups > kPairWaves)
+        a.batchGroups > kPairWaves || (LOC && !a.stripKeys))
         return hipErrorInvalidValue;
     switch (rowsPerStrip - kLo) {
-        case 0: return launchPairStripsCase<kLo, 0>(a, computeUnits, stream);
-        case 2: return launchPairStripsCase<kLo, 2>(a, computeUnits, stream);
-        case 4: return launchPairStripsCase<kLo, 4>(a, computeUnits, stream);
-        case 6: return launchPairStripsCase<kLo, 6>(a, computeUnits, stream);
-        case 8: return launchPairStripsCase<kLo, 8>(a, computeUnits, stream);
-        case 10: return launchPairStripsCase<kLo, 10>(a, computeUnits, stream);
-        case 12: return launchPairStripsCase<kLo, 12>(a, computeUnits, stream);
-        case 14: return launchPairStripsCase<kLo, 14>(a, computeUnits, stream);
+        case 0: return launchPairStripsCase<kLo, 0, LOC>(a, computeUnits, stream);
+        case 2: return launchPairStripsCase<kLo, 2, LOC>(a, computeUnits, stream);
+        case 4: return launchPairStripsCase<kLo, 4, LOC>(a, computeUnits, stream);
+        case 6: return launchPairStripsCase<kLo, 6, LOC>(a, computeUnits, stream);
+        case 8: return launchPairStripsCase<kLo, 8, LOC>(a, computeUnits, stream);
+        case 10: return launchPairStripsCase<kLo, 10, LOC>(a, computeUnits, stream);
+        case 12: return launchPairStripsCase<kLo, 12, LOC>(a, computeUnits, stream);
+        case 14: return launchPairStripsCase<kLo, 14, LOC>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

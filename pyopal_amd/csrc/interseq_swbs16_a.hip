@@ -5,7 +5,7 @@
 namespace miopal {
 
 hipError_t launchInterseqPairSwStripsA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream) {
-    return launchPairStrips<32>(a, rows, computeUnits, stream);
+    return launchPairStrips<32, false>(a, rows, computeUnits, stream);
 }
 
 }  // namespace miopal

@@ -132,6 +132,18 @@ __global__ void decode_keys_kernel(const unsigned long long* keys, int n, int32_
     endJ[k] = key != 0 ? (int)(0xFFFFFFull - ((key >> 16) & 0xFFFFFFull)) : -1;
 }
 
+// keys of the multi-strip pair-table kernel (interseq_impl.h): score << 40 | (0xFFFFF - column) << 20 |
+// (0xFFFFF - row), merged over a group's strips with atomicMax; an untouched key is a score of 0
+__global__ void decode_strip_keys_kernel(const unsigned long long* keys, int n, int32_t* score, int32_t* endI,
+                                         int32_t* endJ) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long key = keys[k];
+    score[k] = (int)(key >> 40);
+    endI[k] = key != 0 ? (int)(0xFFFFFull - (key & 0xFFFFFull)) : -1;
+    endJ[k] = key != 0 ? (int)(0xFFFFFull - ((key >> 20) & 0xFFFFFull)) : -1;
+}
+
 __global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = value;
@@ -153,6 +165,13 @@ hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* scor
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(decode_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ,
                        scoreBias);
+    return hipGetLastError();
+}
+
+hipError_t launchDecodeStripKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
+                                 hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_strip_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ);
     return hipGetLastError();
 }
 

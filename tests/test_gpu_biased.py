@@ -2,6 +2,8 @@
 end locations) against the CPU checker: every strip height, the edges of the exact range (lanes
 that must be flagged and redone), rebasing of the column shift, gap models on both sides of
 open == ext, ragged groups. Bit-exact, through the C ABI."""
+import os
+
 import numpy as np
 import pytest
 
@@ -507,5 +509,119 @@ def test_strips_routing_by_size(capi):
             assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (qlen, hi)
             ref = _oracle.search(q, res[:off[200]], off[:201], B62, 11, 1, "score", "sw")["score"]
             np.testing.assert_array_equal(got[:200], ref)
+    finally:
+        db.close()
+
+
+# --- the strips kernel with end locations (values scaled by 2^bits, the row inside the strip in the low bits) ---
+def strips_end_check(capi, query, res, off, matrix, go, ge, expect=PAIR_STRIPS, modes=("end",), tag=""):
+    db = capi.DeviceDatabase(res, off, 24)
+    routed = None
+    try:
+        for mode in modes:
+            got = db.search(query, matrix, go, ge, mode, "sw")
+            if mode == "end":
+                routed = capi.DeviceDatabase.last_routing()
+            want = _oracle.search(query, res, off, matrix, go, ge, mode, "sw")
+            for key in want:
+                if key == "aln":
+                    for k, (a, b) in enumerate(zip(got[key], want[key])):
+                        assert a.tolist() == b.tolist(), f"{tag} {mode} alignment {k}"
+                else:
+                    np.testing.assert_array_equal(got[key], want[key], err_msg=f"{tag} {mode} {key}")
+    finally:
+        db.close()
+    if expect is not None and routed is not None:
+        assert (routed[1] & 31) == expect, f"{tag}: lane-per-target pass ran {routed[1]}"
+    return routed
+
+
+@pytest.mark.parametrize("qlen", [61, 64, 65, 96, 97, 129, 193, 333, 700])
+def test_strips_end_locations_every_kind_of_strip_count(capi, qlen, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    rng = np.random.default_rng(7000 + qlen)
+    query = _data.random_protein(rng, qlen)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]
+    # related targets whose best cells fall into every strip: pieces of the query from different rows
+    for k in range(24):
+        a = int(rng.integers(0, max(1, qlen - 20)))
+        piece = _data.mutate(rng, query[a:a + int(rng.integers(12, 40))], 0.1)
+        seqs.append(np.concatenate([_data.random_protein(rng, int(rng.integers(0, 40))), piece,
+                                    _data.random_protein(rng, int(rng.integers(0, 40)))]))
+    seqs += [query[: qlen // 2], query[qlen // 3:], np.zeros(0, dtype=np.uint8), query[-5:]]
+    res, off = _oracle.flatten(seqs)
+    strips_end_check(capi, query, res, off, B62, 11, 1, modes=("end", "full"), tag=f"Q={qlen}")
+
+
+def test_strips_end_locations_ties_across_strips(capi, monkeypatch):
+    # the query repeats one block in every strip: a target holding the block once has equally good
+    # alignments ending in the same column at rows of different strips (the smallest row wins), a target
+    # holding it twice has them in different columns too (the smallest column wins)
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    rng = np.random.default_rng(71)
+    block = _data.random_protein(rng, 30)
+    query = np.concatenate([block, _data.random_protein(rng, 14)] * 4)[:170]
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(20, 300, size=200)]
+    for k in range(30):
+        pre, mid, post = (_data.random_protein(rng, int(rng.integers(0, 50))) for _ in range(3))
+        seqs.append(np.concatenate([pre, block, post]))
+        seqs.append(np.concatenate([pre, block, mid, block, post]))
+        seqs.append(np.concatenate([pre, block[:17], post]))
+    res, off = _oracle.flatten(seqs)
+    m = scaled_identity(24, 5, -4)
+    strips_end_check(capi, query, res, off, m, 6, 2, modes=("end", "full"), tag="repeats")
+    strips_end_check(capi, query, res, off, B62, 11, 1, tag="repeats, BLOSUM62")
+
+
+@pytest.mark.parametrize("go,ge", [(3, 1), (11, 1), (1, 1), (2, 5), (5, 0), (14, 12)])
+def test_strips_end_locations_gap_models(capi, go, ge, monkeypatch):
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    rng = np.random.default_rng(go * 100 + ge + 72)
+    query = _data.random_protein(rng, 150)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=300)]
+    seqs += [_data.mutate(rng, query[a:a + 40], 0.2) for a in range(0, 110, 10)]
+    res, off = _oracle.flatten(seqs)
+    strips_end_check(capi, query, res, off, B62, go, ge, expect=None, tag=f"gap {go}/{ge}")
+
+
+def test_strips_end_locations_range_is_left_and_lanes_are_redone(capi, monkeypatch):
+    # strips of 44 rows: 6 row bits, exact below 384; copies of k query residues score 11 k under this
+    # matrix: both sides of the limit, in one strip and across several
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    rng = np.random.default_rng(73)
+    m = scaled_identity(24, 11, -4)
+    query = _data.random_protein(rng, 130)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 300, size=300)]
+    for k in (130, 80, 40, 36, 35, 34, 33, 30, 10):
+        for at in (0, 25, 50):
+            seqs.append(np.concatenate([_data.random_protein(rng, 17), query[at:at + k], _data.random_protein(rng, 9)]))
+    res, off = _oracle.flatten(seqs)
+    routed = strips_end_check(capi, query, res, off, m, 5, 2, modes=("end", "full"), tag="match 11")
+    assert routed[3] >= 12
+
+
+def test_strips_end_locations_probe_declines_scores_in_the_thousands(capi):
+    # long query, long targets, cheap gaps: random pairs score far beyond 384. The twelve longest groups
+    # go through the scores-only kernel first and the search is left to the general kernel; under the
+    # usual gap costs the same search stays on the strips kernel. (Sizes at which the host picks the
+    # strips kernel by itself; the general kernel's own answer is the reference, the checker on a sample.)
+    rng = np.random.default_rng(74)
+    query = _data.random_protein(rng, 600)
+    res, off = _data.random_db(rng, np.full(90_000, 600))
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for go, ge, want in ((3, 1, 1), (11, 1, PAIR_STRIPS)):
+            got = db.search(query, B62, go, ge, "end", "sw")
+            assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (go, ge)
+            ref = _oracle.search(query, res[:off[100]], off[:101], B62, go, ge, "end", "sw")
+            for key in ("score", "end_q", "end_t"):
+                np.testing.assert_array_equal(got[key][:100], ref[key], err_msg=f"{go}/{ge} {key}")
+            os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
+            try:
+                general = db.search(query, B62, go, ge, "end", "sw")
+            finally:
+                del os.environ["MIOPAL_NO_PAIR_STRIPS"]
+            for key in ("score", "end_q", "end_t"):
+                np.testing.assert_array_equal(got[key], general[key], err_msg=f"{go}/{ge} {key}: every target")
     finally:
         db.close()

@@ -15,27 +15,29 @@ ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 os.environ["MIOPAL_PAIR_STRIPS"] = "1"   # also where the host would prefer the general kernel (few units)
 rng = np.random.default_rng(17)
 cases = [
-    ("100k x 2000, Q=2000", np.full(100_000, 2000), 2000, max(1, ITER // 4)),
-    ("1M x 300, Q=300", np.full(1_000_000, 300), 300, ITER),
-    ("log-normal 500k, Q=150", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER),
-    ("30k x 300, Q=640 (few batches, 13 strips)", np.full(30_000, 300), 640, ITER),
+    ("100k x 2000, Q=2000", np.full(100_000, 2000), 2000, max(1, ITER // 4), "score"),
+    ("1M x 300, Q=300", np.full(1_000_000, 300), 300, ITER, "score"),
+    ("1M x 300, Q=300, end locations", np.full(1_000_000, 300), 300, ITER, "end"),
+    ("log-normal 500k, Q=150", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER, "score"),
+    ("log-normal 500k, Q=150, end locations", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER, "end"),
+    ("30k x 300, Q=640 (few batches, 13 strips)", np.full(30_000, 300), 640, ITER, "score"),
 ]
-for name, lengths, Q, iters in cases:
+for name, lengths, Q, iters, mode in cases:
     res, off = _data.random_db(rng, lengths)
     q = _data.random_protein(rng, Q)
     db = _capi.DeviceDatabase(res, off, 24)
     os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
-    want = db.search(q, m, 3, 1, "score", "sw")["score"]
+    want = db.search(q, m, 3, 1, mode, "sw")
     assert (_capi.DeviceDatabase.last_routing()[1] & 15) == 1
     os.environ.pop("MIOPAL_NO_PAIR_STRIPS")
     bad = 0
     t0 = time.perf_counter()
     for k in range(iters):
-        got = db.search(q, m, 3, 1, "score", "sw")["score"]
+        got = db.search(q, m, 3, 1, mode, "sw")
         assert _capi.DeviceDatabase.last_routing()[1] == 6
-        if not np.array_equal(got, want):
+        if not all(np.array_equal(got[key], want[key]) for key in want):
             bad += 1
-            print(f"  {name}: run {k}: {int((got != want).sum())} scores differ", flush=True)
+            print(f"  {name}: run {k}: {sum(int((got[key] != want[key]).sum()) for key in want)} values differ", flush=True)
     print(f"{name}: {iters} runs, {bad} with differences, {(time.perf_counter() - t0) / iters * 1e3:.2f} ms per search", flush=True)
     db.close()
     assert bad == 0
