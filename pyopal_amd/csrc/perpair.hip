@@ -66,8 +66,13 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
 
     // running answer over the strips: (score, column, row) of the first maximum
     int best = INT32_MIN, brow = -1, bcol = -1;
-    const bool stopOn = (job.rules & kRuleStop) && nStrips == 1;
+    // The known optimum ends the scan: the first cell that holds it is the first maximum. With several
+    // strips the columns a lane still needs shrink instead: once a strip has met the optimum in column c
+    // the strips below can only beat it in a smaller column (their rows are larger), so they - and the
+    // rows handed down to them - stop at c.
+    const bool stopOn = (job.rules & kRuleStop) != 0;
     const int stopScore = job.stop;
+    int need = L;   // columns this lane still has to sweep
     const uint8_t* tptr = a.residues + job.tOff;
     const int64_t tStep = job.tStep;
     // strip boundaries of the wavefront: (H - open, F) of the strip's last row, per column
@@ -103,7 +108,15 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
         int aboveHmPrev = (s == 0 ? 0 : borderGap(row0 - 1, open, ext)) - open;
 
         int tcolNext = (L > 0 ? (int)tptr[0] : A) * 4;
-        for (int j = 0; j < maxL; ++j) {
+        int maxNeed = MODE == kPerPairTrace ? L : need;   // wave-uniform bound of this strip's sweep
+        if (MODE != kPerPairTrace) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) maxNeed = max(maxNeed, __shfl_xor(maxNeed, off));
+            maxNeed = __builtin_amdgcn_readfirstlane(maxNeed);
+        } else {
+            maxNeed = maxL;
+        }
+        for (int j = 0; j < maxNeed; ++j) {
             const int tcol = tcolNext;
             {
                 int t = A;
@@ -175,8 +188,9 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
                 scol = sbest != bestBefore ? j : scol;  // candidates only ever raise `sbest`
                 // the optimum of the forward pass is the first maximum of this scan: a lane that
                 // met it is finished; the wavefront leaves when no lane has work left
-                const bool more = j + 1 < L && !(stopOn && sbest == stopScore);
-                if (__builtin_amdgcn_ballot_w64(more) == 0 && !toNext) break;
+                // (also with a strip below: it needs no column beyond the ones every lane still needed here)
+                const bool more = j + 1 < need && !(stopOn && sbest == stopScore);
+                if (__builtin_amdgcn_ballot_w64(more) == 0) break;
             }
         }
         if (MODE != kPerPairTrace && Q > row0 && scol >= 0) {
@@ -187,6 +201,7 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
                 bcol = scol;
             }
         }
+        if (MODE != kPerPairTrace && stopOn && best == stopScore) need = min(need, bcol + 1);
     }
 
     if (active) {
