@@ -514,18 +514,27 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
         __syncthreads();
     }
     int run = partial[threadIdx.x] - sum;
+    // bins[b] becomes the number of jobs with a key above b (non-increasing in b). The 90th percentile,
+    // the smallest key with at most 10 % of the jobs above it, is found on the way: every thread
+    // looks at the bins it rewrites (one thread walking the bins through global memory took 0.3 ms).
+    __shared__ int p90Shared;
+    if (threadIdx.x == 0) p90Shared = maxLen;
+    __syncthreads();
+    int mine = maxLen;
     for (int r = threadIdx.x * per; r < min(nBins, (threadIdx.x + 1) * per); ++r) {
-        const int c = bins[maxLen - r];
-        bins[maxLen - r] = run;
+        const int b = maxLen - r;
+        const int c = bins[b];
+        bins[b] = run;
+        if (run <= n / 10) mine = min(mine, b);
         run += c;
     }
     if (headWaves != nullptr) {
-        // bins[b] is now the number of jobs with a key above b. Outliers: keys above twice the
-        // 90th percentile (and above 64 residues).
+        // Outliers: keys above twice the 90th percentile (and above 64 residues).
+        // p90 = the smallest key b with bins[b] <= n / 10, i.e. at most 10 % of the jobs above it
+        if (mine < maxLen) atomicMin(&p90Shared, mine);
         __syncthreads();
         if (threadIdx.x == 0) {
-            int p90 = maxLen;
-            while (p90 > 0 && bins[p90 - 1] <= n / 10) --p90;   // smallest key with <= 10 % above it
+            const int p90 = p90Shared;
             const int floorKey = 64 >> shift;
             const int longKey = max(2 * p90, floorKey) + 1;      // outliers have key >= longKey
             int count = 0;
