@@ -249,7 +249,19 @@ struct Workspace {
 
     int ensureAux() {
         if (aux) return 0;
-        HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+        // A stream of its own PRIORITY: the runtime multiplexes the streams of a process onto four
+        // hardware queues per priority level, and two streams that share a queue run in order. With
+        // a handful of streams alive (workspaces, view construction, the upload pool) the side stream
+        // and its workspace's main stream sometimes landed on one queue: the kernel that should run
+        // BESIDE the packed one ran after it (log-normal database, NW at Q = 150: 7.0 instead of 4.0 ms).
+        // The work on this stream is the launch's critical path anyway.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+            (void)hipGetLastError();
+            least = greatest = 0;
+        }
+        if (greatest != least) HIP_TRY(hipStreamCreateWithPriority(&aux, hipStreamNonBlocking, greatest));
+        else HIP_TRY(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&evFork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&evJoin, hipEventDisableTiming));
         return 0;
@@ -1641,6 +1653,12 @@ struct Search {
                 int pairUnits = db->computeUnits;
                 if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
+                else if (forked)
+                    // The persistent workgroups hold their CU's registers for the whole launch: the
+                    // wavefront-per-pair kernel on the side stream only finds room as they leave, i.e. it
+                    // runs AFTER the packed kernel (log-normal lengths, NW at Q = 53, 6400 pairs on the side:
+                    // 2.07 ms; with CUs kept out of the persistent launch 1.66 ms). One CU per 256 pairs.
+                    pairUnits = std::max(1, pairUnits - (int)std::min<int64_t>(pairUnits / 4, std::max<int64_t>(8, (g_lastRouting[0] + 255) / 256)));
                 g_lastRouting[1] = 2 + (int)kPairSwStrips;
                 // few (group, strip) units: fewer groups per workgroup, so that every CU gets a unit and a
                 // wavefront shares its SIMD with fewer others
@@ -1702,6 +1720,12 @@ struct Search {
                 int pairUnits = db->computeUnits;
                 if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
+                else if (forked)
+                    // The persistent workgroups hold their CU's registers for the whole launch: the
+                    // wavefront-per-pair kernel on the side stream only finds room as they leave, i.e. it
+                    // runs AFTER the packed kernel (log-normal lengths, NW at Q = 53, 6400 pairs on the side:
+                    // 2.07 ms; with CUs kept out of the persistent launch 1.66 ms). One CU per 256 pairs.
+                    pairUnits = std::max(1, pairUnits - (int)std::min<int64_t>(pairUnits / 4, std::max<int64_t>(8, (g_lastRouting[0] + 255) / 256)));
                 // groups of similar length: every SIMD takes the same share of them (interseq_impl.h)
                 {
                     const int blocks = std::max(1, std::min(pairUnits, ia.nGroups));
