@@ -79,6 +79,19 @@ struct PhaseTimer {
     }
 };
 
+// Streams that only carry uploads (database pieces, view construction) are created at the LOWEST
+// priority: the runtime multiplexes streams onto four hardware queues per priority level, and every
+// stream left at the default level makes it likelier that two workspaces' search streams share one.
+inline hipError_t createUploadStream(hipStream_t* s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        least = greatest = 0;
+    }
+    if (least > 0) return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 2ll << 30;  // direction workspace: 2 x this per device-resident traceback batch, 1 x per host-built batch
 constexpr int64_t kInt32Safe = 1ll << 29;
@@ -560,7 +573,7 @@ struct StagingPool {
         std::unique_ptr<StreamSet> set(new StreamSet());
         set->device = device;
         for (hipStream_t& x : set->s)
-            if (hipStreamCreateWithFlags(&x, hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (createUploadStream(&x) != hipSuccess) return nullptr;
         return set;
     }
     void giveStreams(std::unique_ptr<StreamSet> set) {
@@ -731,7 +744,7 @@ struct UploadLease {
         }
         if (!ch) {
             ch.reset(new MiopalDb::UploadChannel());
-            HIP_TRY(hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking));
+            HIP_TRY(createUploadStream(&ch->stream));
         }
         if (ch->cap < bytes) {
             if (ch->pinned) HIP_TRY(hipHostFree(ch->pinned));
