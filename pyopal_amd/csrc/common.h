@@ -95,6 +95,12 @@ struct IntraseqArgs {
     const int* headWaves;     // null: every job, addressed through the job itself
     int64_t headDirStride;    // direction bytes per job
     int64_t headWsStride;     // boundary columns per job
+    // intraseq_strips_kernel (long pairs, one wavefront per (pair, strip) unit):
+    int nStrips;              // strips of every pair of the launch
+    int* stripCounter;        // zeroed: next unit
+    int* stripProgress;       // zeroed, [nJobs x nStrips]: columns of the strip's last row published
+    int4* stripPartial;       // [nJobs x nStrips]: (score, row, column) of the strip
+    int* error;               // incremented by a unit that gave up waiting (never seen)
 };
 
 struct WalkArgs {
@@ -230,6 +236,7 @@ hipError_t launchInterseqUnsignedDiag(const InterseqArgs& a, int rowsPerStrip, i
 hipError_t launchInterseqUnsignedDiagLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchInterseqSignedAllLoc(const InterseqArgs& a, int rowsPerStrip, int waves, hipStream_t stream);
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream);
+hipError_t launchIntraseqStrips(const IntraseqArgs& a, hipStream_t stream);
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream);
 hipError_t launchStartCells(int n, int mode, int open, int ext, const int32_t* score, const int32_t* endQ,
                             const int32_t* endT, const int32_t* rScore, const int32_t* rI, const int32_t* rJ,

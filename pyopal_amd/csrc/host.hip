@@ -160,7 +160,8 @@ struct HostBytes {
 enum Slot {
     kQuery, kMatrix, kProfile, kViewScore, kViewOvf, kCounter, kBoundary0, kBoundary1,
     kScore, kEndI, kEndJ, kJobs, kPairB0, kPairB1, kAuxJobs, kAuxPairB0, kAuxPairB1, kRScore, kRI, kRJ, kDirs, kOps, kOpsOff,
-    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kUnitState, kUnitPartial, kStripKeys, kSlots
+    kOpsLen, kOvfHost, kWorkCounter, kViewEndI, kViewEndJ, kStartQ, kStartT, kMismatch, kCompactOps, kTraceScore, kOpsTotals, kSortBins, kSortedJobs, kKeys, kHeadWaves, kHeadDirs, kUnitState, kUnitPartial, kStripKeys,
+    kPairStripState, kPairStripPartial, kPairStripSpare, kAuxPairStripState, kAuxPairStripPartial, kPairStripError, kSlots
 };
 
 struct Workspace {
@@ -1075,6 +1076,8 @@ struct Search {
     int64_t balancedChunks = 0;
     bool globalPairRefused = false;   // the pair-table launch for NW / HW / OV failed on this device
     bool pairStripsRefused = false;   // the same for the multi-strip Smith-Waterman kernel
+    int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
+    int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
 
     uint8_t* d_query = nullptr;
@@ -1161,6 +1164,35 @@ struct Search {
         a.endI = d_endI;
         a.endJ = d_endJ;
         a.raisePriority = (on != stream && !getenv("MIOPAL_NO_PRIORITY")) ? 1 : 0;
+        // Pairs of several strips, scores / end locations: one wavefront per (pair, strip), the strips of
+        // a pair side by side (intraseq.hip) - a pair is then a chain of L + 63 steps, not strips x that.
+        // Worth it while the pairs are few against the chip (a chain is what is waited for); thousands of
+        // pairs fill the chip either way.
+        bool uniform = !trace && !jobs.empty() && jobs[0].qLen > kLanes && !getenv("MIOPAL_NO_PAIR_STRIP_UNITS");
+        for (const auto& j : jobs)
+            if (j.qLen != jobs[0].qLen) uniform = false;
+        const int jobStrips = uniform ? (jobs[0].qLen + kLanes - 1) / kLanes : 1;
+        if (uniform && jobStrips >= 2 && (int64_t)jobs.size() * jobStrips <= (1 << 20) &&
+            (int64_t)jobs.size() <= 16 * (int64_t)db->computeUnits) {
+            void *st, *pt;
+            const size_t ints = jobs.size() * (size_t)jobStrips + 1;
+            RC_TRY(ws->get(kPairStripState + slotBase, ints * sizeof(int), &st));
+            RC_TRY(ws->get(kPairStripPartial + slotBase, (ints - 1) * sizeof(int4), &pt));
+            HIP_TRY(hipMemsetAsync(st, 0, ints * sizeof(int), on));
+            if (!d_stripError) {
+                void* pe;
+                RC_TRY(ws->get(kPairStripError, sizeof(int), &pe));
+                HIP_TRY(hipMemsetAsync(pe, 0, sizeof(int), on));
+                d_stripError = (int*)pe;
+            }
+            a.nStrips = jobStrips;
+            a.stripCounter = (int*)st;
+            a.stripProgress = (int*)st + 1;
+            a.stripPartial = (int4*)pt;
+            a.error = d_stripError;
+            HIP_TRY(launchIntraseqStrips(a, on));
+            return 0;
+        }
         HIP_TRY(launchIntraseq(a, trace, on));
         return 0;
     }
@@ -1493,9 +1525,19 @@ struct Search {
                 // longest packed target that the plain flavour can take (view order: longest first)
                 int firstFit = firstPos;
                 while (firstFit < view->nPacked && !fitsPlain(dbLen(db, view->ids[firstFit]))) ++firstFit;
-                const bool diag = firstFit < view->nPacked && fitsDiag(dbLen(db, view->ids[firstFit])) &&
-                                  !getenv("MIOPAL_NO_DIAG_SHIFT");
-                if (diag) {
+                // The shifted flavours need more head-room, i.e. shorter targets. A few targets too long
+                // for them would put the WHOLE view on the plain int16 lanes (8 operations per cell pair
+                // instead of 5: cfg4 with the reference's 1000 .. 35000 tail, NW: 78 ms instead of 48); the
+                // int32 kernel takes a long pair in a few milliseconds now (one wavefront per strip), so up
+                // to 1024 of the longest targets are handed to it when that buys the view a cheaper flavour.
+                auto firstThat = [&](int from, auto&& fits) {
+                    int p = from;
+                    while (p < view->nPacked && p - from <= 1024 && !fits(dbLen(db, view->ids[p]))) ++p;
+                    return (p < view->nPacked && p - from <= 1024 && dbLen(db, view->ids[p]) > 0) ? p : -1;
+                };
+                const int firstDiag = getenv("MIOPAL_NO_DIAG_SHIFT") ? -1 : firstThat(firstFit, fitsDiag);
+                if (firstDiag >= 0) {
+                    firstFit = firstDiag;
                     flavour = kSignedInt16Diag;
                     profileShift = 2 * ext;
                     // The same shift on unsigned patterns compared as half floats (ArithU16Diag: integer
@@ -1503,16 +1545,20 @@ struct Search {
                     // (s + ext + open >= 0), open >= ext, and every pattern
                     // zero + x + (i + j) ext within [0, 0x7BFF] for the longest target that stays packed.
                     const int64_t c = (int64_t)open - ext;
-                    const int64_t Lfit = dbLen(db, view->ids[firstFit]);
-                    const int64_t top = kUnsignedDiagZero + std::min<int64_t>(Q, Lfit) * pos + (Q + Lfit + 2) * (int64_t)ext +
-                                        pos + 2 * (int64_t)ext + c;
                     const int64_t below = 3 * (int64_t)open + 2 * (int64_t)ext + std::max(0, -minScore) + c;
-                    if (c >= 0 && (int64_t)minScore + ext + open >= 0 && top < 0x7C00 &&
+                    auto fitsUnsigned = [&](int64_t L) {
+                        return L > 0 && kUnsignedDiagZero + std::min<int64_t>(Q, L) * pos + (Q + L + 2) * (int64_t)ext + pos +
+                                                2 * (int64_t)ext + c < 0x7C00;
+                    };
+                    if (c >= 0 && (int64_t)minScore + ext + open >= 0 &&
                         0x0400 + below + 64 <= kUnsignedDiagZero &&   // real cells stay above the padding cells' floor
-
                         !getenv("MIOPAL_NO_UNSIGNED_DIAG")) {
-                        flavour = kUnsignedDiag;
-                        profileShift = 2 * ext + (int)c;
+                        const int firstU = firstThat(firstFit, fitsUnsigned);
+                        if (firstU >= 0) {
+                            firstFit = firstU;
+                            flavour = kUnsignedDiag;
+                            profileShift = 2 * ext + (int)c;
+                        }
                     }
                 }
                 // the targets that do not fit form a prefix of the view, empty targets (closed
@@ -2147,8 +2193,12 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         RC_TRY(ws->stageDownload(endQuery, pi, (size_t)n * sizeof(int)));
         RC_TRY(ws->stageDownload(endTarget, pj, (size_t)n * sizeof(int)));
     }
+    if (s.d_stripError) RC_TRY(ws->stageDownload(&s.stripErrorHost, s.d_stripError, sizeof(int)));
     RC_TRY(ws->finishDownloads());
     HIP_TRY(hipStreamSynchronize(stream));
+    if (s.stripErrorHost != 0)
+        return fail(MIOPAL_ERR_INTERNAL, "%d (pair, strip) units of the wavefront-per-pair kernel gave up waiting for the strip above",
+                    s.stripErrorHost);
     pt.mark("score/end pass + D2H");
     if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
 

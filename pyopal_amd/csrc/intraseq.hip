@@ -222,6 +222,218 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     }
 }
 
+// ---- long pairs, strip-parallel --------------------------------------------------------------
+// intraseq_kernel sweeps the strips of a pair one after the other: a chain of strips x (L + 63)
+// dependent steps of ~600 cycles each, however many wavefronts the chip has. The 35 000-residue
+// target of BASELINE configs[3] against the 2000-residue query is 32 strips: 280 ms for one pair,
+// five times the rest of the search. Here a wavefront owns ONE (pair, strip) unit, taken from a
+// counter pair-major, and the strips of a pair run side by side: strip s follows strip s - 1 through
+// the boundary row in HBM, block of 64 columns by block, behind a progress counter - the scheme of
+// interseq_pair_strips_kernel (relaxed agent-scope atomics for the rows, which cross XCDs; every
+// taken unit's producer was taken before it, strip 0 waits for nobody). The chain becomes L + 63
+// steps plus two blocks of lag per strip. Each unit leaves (score, row, column) of its strip;
+// merge_strip_partials_kernel folds them with the tie-breaks of the wave reduction. Scores and end
+// locations only (no direction bytes), pairs of one common number of strips.
+constexpr int kStripWaitCap = 1 << 22;   // x s_sleep 4: about two seconds, then the unit gives up (a.error)
+
+__global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel(IntraseqArgs a) {
+    __shared__ int smat[kMaxAlphabet * kMatStride];
+    const int A = a.alphabet;
+    for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x)
+        smat[(idx / A) * kMatStride + (idx % A)] = a.matrix[idx];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    int unit = 0;
+    if (lane == 0) unit = atomicAdd(a.stripCounter, 1);
+    unit = __builtin_amdgcn_readfirstlane(unit);
+    const int nStrips = a.nStrips;
+    if (unit >= a.nJobs * nStrips) return;
+    const int jobIdx = unit / nStrips, s = unit - jobIdx * nStrips;
+    const PairJob job = a.jobs[jobIdx];
+    const int Q = job.qLen, L = job.tLen;
+    int4* partial = a.stripPartial + unit;
+    int* progOut = a.stripProgress + unit;
+    const int* progIn = progOut - 1;
+    if (s * kLanes >= Q || L <= 0) {
+        // (a pair with fewer strips than the launch's, or an empty target: nothing in this strip)
+        if (lane == 0) {
+            *partial = make_int4(0, -1, -1, 0);
+            __hip_atomic_store(progOut, L > 0 ? L : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
+    const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
+    const int region = (job.rules >> 4) & 3;
+    const int open = a.gapOpen, ext = a.gapExt;
+    const uint8_t* tptr = a.residues + job.tOff;
+    const uint8_t* qptr = a.query + job.qOff;
+    const int jobStrips = (Q + kLanes - 1) / kLanes;
+    const int i = s * kLanes + lane;
+    const bool rowActive = i < Q;
+    const int qres = rowActive ? qptr[(int64_t)i * job.qStep] : 0;
+    const int* srow = smat + qres * kMatStride;
+    int hLeft = leftGap ? borderGap(i, open, ext) : 0;  // H[i][-1]
+    int eLeft = kNegInf;
+    int hDiag = (i == 0) ? 0 : (leftGap ? borderGap(i - 1, open, ext) : 0);  // H[i-1][-1]
+    int fCur = kNegInf;
+    unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + job.wsOff);
+    unsigned long long* bout = reinterpret_cast<unsigned long long*>(a.boundary[s & 1] + job.wsOff);
+    const bool lastStrip = s + 1 == jobStrips;
+    const bool rowIsLast = i == Q - 1;
+    const bool candAlways = rowActive && (region == kAllCells || (rowIsLast && region != kLastCell));
+    const bool candOnLastCol = rowActive && (region == kLastRowCol || (region == kLastCell && rowIsLast));
+    const bool writer = lane == kLanes - 1 && !lastStrip;
+    int best = floor0 ? 0 : INT32_MIN, bi = -1, bj = -1;
+
+    constexpr int kShr1 = 0x138, kRol1 = 0x134;
+    int tres = lane == 0 ? (int)tptr[0] : 0;
+    int scCur = srow[tres];
+    int tbuf = 0, bH = 0, bF = kNegInf;
+    int topOne = open, topMany = open;
+    const int rows = min(Q - s * kLanes, kLanes);
+    const int kLimit = L + rows - 1;
+    int avail = s == 0 ? L : 0;   // columns of the row above known to be published
+    bool dead = false;
+    for (int k0 = 0; k0 < kLimit && !dead; k0 += kLanes) {
+        {
+            const int kt = k0 + 1 + lane;
+            tbuf = kt < L ? tptr[(int64_t)kt * job.tStep] : 0;
+            if (s > 0) {
+                const int need = min(k0 + kLanes, L);
+                int spins = 0;
+                while (avail < need) {
+                    const int v = __hip_atomic_load(const_cast<int*>(progIn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    avail = __builtin_amdgcn_readfirstlane(v);
+                    if (avail >= need) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > kStripWaitCap) {
+                        dead = true;
+                        break;
+                    }
+                }
+                if (dead) break;
+                const int kb = k0 + lane;
+                if (kb < L) {
+                    const unsigned long long v = __hip_atomic_load(bin + kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bH = (int)(uint32_t)v;
+                    bF = (int)(uint32_t)(v >> 32);
+                } else {
+                    bH = 0;
+                    bF = kNegInf;
+                }
+            }
+        }
+        const int kEnd = min(k0 + kLanes, kLimit);
+        for (int k = k0; k < kEnd; ++k) {
+            const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
+            tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
+            const int scNext = srow[tnext];
+            tres = tnext;
+            int hTop = bH, fTop = bF;
+            if (s == 0) {
+                hTop = topGap ? -min(topOne, topMany) : 0;
+                fTop = kNegInf;
+                topOne += ext;
+                topMany += open;
+            } else {
+                bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
+                bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
+            }
+            const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
+            const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
+            const int j = k - lane;
+            const int eOpen = hLeft - open, eExt = eLeft - ext;
+            const int fOpen = hUp - open, fExt = fUp - ext;
+            const int e = max(eOpen, eExt);
+            const int f = max(fOpen, fExt);
+            const int d = hDiag + scCur;
+            int h = max(d, max(e, f));
+            if (floor0) h = max(h, 0);
+            const bool started = j >= 0;
+            hDiag = hUp;
+            hLeft = started ? h : hLeft;
+            eLeft = started ? e : eLeft;
+            fCur = started ? f : fCur;
+            const bool inside = (unsigned)j < (unsigned)L;
+            const bool take = inside && (candAlways || (candOnLastCol && j == L - 1)) &&
+                              (h > best || (h == best && j < bj));
+            best = take ? h : best;
+            bi = take ? i : bi;
+            bj = take ? j : bj;
+            if (writer && inside)
+                __hip_atomic_store(bout + j, ((unsigned long long)(uint32_t)f << 32) | (uint32_t)h, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            scCur = scNext;
+        }
+        if (!lastStrip) {
+            // columns written so far by lane 63: j = k - 63 for the steps done
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            const int done = min(max(kEnd - (kLanes - 1), 0), L);
+            if (lane == 0) __hip_atomic_store(progOut, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (dead) {
+        // (never seen: the strip above was taken before this one and waits for nobody below it)
+        if (lane == 0) {
+            atomicAdd(a.error, 1);
+            *partial = make_int4(0, -1, -1, 0);
+            __hip_atomic_store(progOut, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // wave reduction: highest score, then smallest column, then smallest row
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int os = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+        const bool mineEmpty = bi < 0, otherEmpty = oi < 0;
+        bool take;
+        if (otherEmpty) take = false;
+        else if (mineEmpty) take = !floor0 || os > best;
+        else take = better(os, oj, oi, best, bj, bi);
+        if (take) {
+            best = os;
+            bi = oi;
+            bj = oj;
+        }
+    }
+    if (lane == 0) *partial = make_int4(best, bi, bj, 0);
+}
+
+// One thread per pair: the strips' answers folded in strip order with the rule of the wave reduction.
+__global__ void merge_strip_partials_kernel(IntraseqArgs a) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.nJobs) return;
+    const PairJob job = a.jobs[k];
+    const bool floor0 = job.rules & 4;
+    int best = floor0 ? 0 : INT32_MIN, bi = -1, bj = -1;
+    const bool degenerate = job.qLen <= 0 || job.tLen <= 0;
+    if (degenerate && !floor0) {
+        // closed forms of the border (oracle/opal_oracle.c, dp_pass), as in intraseq_kernel
+        const bool topGap = job.rules & 1, leftGap = job.rules & 2;
+        best = 0;
+        if (job.qLen > 0) best = leftGap ? borderGap(job.qLen - 1, a.gapOpen, a.gapExt) : 0;
+        if (job.tLen > 0) best = topGap ? borderGap(job.tLen - 1, a.gapOpen, a.gapExt) : 0;
+    }
+    for (int s = 0; s < a.nStrips && !degenerate; ++s) {
+        const int4 p = a.stripPartial[(size_t)k * a.nStrips + s];
+        const bool mineEmpty = bi < 0, otherEmpty = p.y < 0;
+        bool take;
+        if (otherEmpty) take = false;
+        else if (mineEmpty) take = !floor0 || p.x > best;
+        else take = better(p.x, p.z, p.y, best, bj, bi);
+        if (take) {
+            best = p.x;
+            bi = p.y;
+            bj = p.z;
+        }
+    }
+    a.score[job.out] = best;
+    if (a.endI) a.endI[job.out] = bi;
+    if (a.endJ) a.endJ[job.out] = bj;
+}
+
 // One thread per pair: walk the direction bytes back from the end cell. Every memory access of
 // a step is divergent (64 lanes, 64 lines), so the step is kept to ONE such access, the
 // direction byte: the query sits in LDS, the target residues are fetched four at a time, and
@@ -631,6 +843,18 @@ hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream)
         hipLaunchKernelGGL((intraseq_kernel<true>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
     else
         hipLaunchKernelGGL((intraseq_kernel<false>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchIntraseqStrips(const IntraseqArgs& a, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    if (a.nStrips < 2 || !a.stripCounter || !a.stripProgress || !a.stripPartial || !a.error || !a.boundary[0] || !a.boundary[1])
+        return hipErrorInvalidValue;
+    const int64_t units = (int64_t)a.nJobs * a.nStrips;
+    if (units > INT32_MAX / 2) return hipErrorInvalidValue;
+    const int blocks = (int)((units + kJobsPerBlock - 1) / kJobsPerBlock);
+    hipLaunchKernelGGL(intraseq_strips_kernel, dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+    hipLaunchKernelGGL(merge_strip_partials_kernel, dim3((a.nJobs + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -581,3 +581,28 @@ def test_outlier_windows_in_the_direction_pass(capi):
         np.testing.assert_array_equal(got[key][sample], ref[key], err_msg=key)
     for x, k in enumerate(sample):
         assert got["aln"][int(k)].tolist() == ref["aln"][x].tolist(), f"alignment of target {k}"
+
+
+@pytest.mark.parametrize("qlen", [65, 128, 129, 300])
+def test_long_pairs_one_wavefront_per_strip(capi, qlen, monkeypatch):
+    """The wavefront-per-pair int32 kernel with the strips of a pair side by side (intraseq_strips_kernel):
+    targets too long for a lane each (> 8192 residues), all modes, scores and end locations, lengths
+    that are no multiple of the 64-column blocks, repeats (ties between strips) - against the checker and
+    against the strip-after-strip kernel it replaces. Shorter targets beside them stay on the packed kernel."""
+    rng = np.random.default_rng(500 + qlen)
+    query = np.concatenate([_data.random_protein(rng, 40)] * 8)[:qlen]   # repeats: equal scores in different strips
+    long_ones = [_data.random_protein(rng, int(n)) for n in (8193, 8200, 8255, 8256, 8257, 9001)]
+    long_ones.append(np.concatenate([_data.random_protein(rng, 4000), np.tile(query[:40], 6), _data.random_protein(rng, 4100)]))
+    long_ones.append(np.concatenate([_data.random_protein(rng, 8100), _data.mutate(rng, query, 0.1), _data.random_protein(rng, 77)]))
+    seqs = long_ones + [_data.random_protein(rng, int(n)) for n in (1, 64, 700)] + [np.zeros(0, dtype=np.uint8)]
+    res, off = _oracle.flatten(seqs)
+    for algo in ALGOS:
+        for mode in ("score", "end"):
+            gpu, ref = run_both(capi, query, res, off, B62, 11, 1, mode, algo)
+            compare(gpu, ref, mode, f"strip units {algo}/{mode}/Q={qlen}")
+            if algo in ("nw", "ov"):   # (SW and HW searches see long targets through windows on the packed kernel)
+                assert capi.DeviceDatabase.last_routing()[0] >= len(long_ones)   # the long pairs went to the int32 kernel
+            monkeypatch.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
+            old, _ = run_both(capi, query, res, off, B62, 11, 1, mode, algo)
+            monkeypatch.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
+            compare(old, ref, mode, f"strip after strip {algo}/{mode}/Q={qlen}")
