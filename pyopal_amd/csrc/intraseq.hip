@@ -11,6 +11,7 @@
 //
 // Model and tie-breaks: oracle/opal_oracle.c.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     // it should win the SIMD's issue arbitration, it needs few slots
     if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
     const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
+    const int hFloor = floor0 ? 0 : INT32_MIN;   // Smith-Waterman floor as a max that is always there
     const int region = (job.rules >> 4) & 3;
     const int open = a.gapOpen, ext = a.gapExt;
 
@@ -124,72 +126,85 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
                     }
                 }
                 const int kEnd = min(k0 + kLanes, kLimit);
-                for (int k = k0; k < kEnd; ++k) {
-                    // residue stage of step k + 1
-                    const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
-                    tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
-                    const int scNext = srow[tnext];
-                    tres = tnext;
+                // The step is a chain of dependent operations on ONE wavefront: every taken branch is a
+                // bubble nothing else fills. The loop is compiled per kind of strip (first: border sums;
+                // later: the row above from the lane buffers) and with / without the stop rule, the floor
+                // is a max with 0 or INT32_MIN, the candidate test is mask arithmetic.
+                auto steps = [&](auto firstC, auto stopC) {
+                    constexpr bool kFirst = decltype(firstC)::value, kStop = decltype(stopC)::value;
+                    for (int k = k0; k < kEnd; ++k) {
+                        // residue stage of step k + 1
+                        const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
+                        tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
+                        const int scNext = srow[tnext];
+                        tres = tnext;
 
-                    // DP stage of step k
-                    int hTop = bH, fTop = bF;
-                    if (s == 0) {
-                        hTop = topGap ? -min(topOne, topMany) : 0;
-                        fTop = kNegInf;
-                        topOne += ext;
-                        topMany += open;
-                    } else {
-                        bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
-                        bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
-                    }
-                    const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
-                    const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
-                    const int j = k - lane;
-                    const int eOpen = hLeft - open, eExt = eLeft - ext;
-                    const int fOpen = hUp - open, fExt = fUp - ext;
-                    const int e = max(eOpen, eExt);
-                    const int f = max(fOpen, fExt);
-                    const int d = hDiag + scCur;
-                    int h = max(d, max(e, f));
-                    if (floor0) h = max(h, 0);
-                    if (TRACE) {
-                        // priority diag > E (target gap) > F (query gap); inside a gap,
-                        // closing it (back to H) is preferred to extending it
-                        const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
-                        dirs[(size_t)k * kLanes + lane] =
-                            (uint8_t)(which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0));
-                    }
-                    // a lane that has not reached its first column keeps its borders; past its
-                    // last column nothing reads its state any more
-                    const bool started = j >= 0;
-                    hDiag = hUp;
-                    hLeft = started ? h : hLeft;
-                    eLeft = started ? e : eLeft;
-                    fCur = started ? f : fCur;
-                    // candidates: inside a strip a lane's columns come in order, but the lane's row
-                    // of a later strip may tie with an earlier strip's best at a smaller column;
-                    // ties between lanes are settled at the end
-                    const bool inside = (unsigned)j < (unsigned)L;
-                    const bool take = inside && (candAlways || (candOnLastCol && j == L - 1)) &&
-                                      (h > best || (h == best && j < bj));
-                    best = take ? h : best;
-                    bi = take ? i : bi;
-                    bj = take ? j : bj;
-                    if (writer && inside) bout[j] = make_int2(h, f);
-                    scCur = scNext;
-                    if (stopEnabled) {
-                        // First maximum of the column-major scan = the first column holding the
-                        // (known) optimum: once a lane meets it in column c, only the steps that
-                        // complete columns <= c can still change the answer.
-                        const bool hit = take && h == stopScore;
-                        if (__builtin_amdgcn_ballot_w64(hit)) {
-                            int c = hit ? j : INT32_MAX;
-#pragma unroll
-                            for (int off = 32; off > 0; off >>= 1) c = min(c, __shfl_xor(c, off));
-                            kLimit = min(kLimit, __builtin_amdgcn_readfirstlane(c) + rows);
+                        // DP stage of step k
+                        int hTop = bH, fTop = bF;
+                        if constexpr (kFirst) {
+                            hTop = topGap ? -min(topOne, topMany) : 0;
+                            fTop = kNegInf;
+                            topOne += ext;
+                            topMany += open;
+                        } else {
+                            bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
+                            bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
                         }
-                        if (k + 1 >= kLimit) break;
+                        const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
+                        const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
+                        const int j = k - lane;
+                        const int eOpen = hLeft - open, eExt = eLeft - ext;
+                        const int fOpen = hUp - open, fExt = fUp - ext;
+                        const int e = max(eOpen, eExt);
+                        const int f = max(fOpen, fExt);
+                        const int d = hDiag + scCur;
+                        const int h = max(max(d, hFloor), max(e, f));
+                        if (TRACE) {
+                            // priority diag > E (target gap) > F (query gap); inside a gap,
+                            // closing it (back to H) is preferred to extending it
+                            const int which = (h == d) ? 0 : (h == e) ? 1 : 2;
+                            dirs[(size_t)k * kLanes + lane] =
+                                (uint8_t)(which | (e == eOpen ? 4 : 0) | (f == fOpen ? 8 : 0));
+                        }
+                        // a lane that has not reached its first column keeps its borders; past its
+                        // last column nothing reads its state any more
+                        const bool started = j >= 0;
+                        hDiag = hUp;
+                        hLeft = started ? h : hLeft;
+                        eLeft = started ? e : eLeft;
+                        fCur = started ? f : fCur;
+                        // candidates: inside a strip a lane's columns come in order, but the lane's row
+                        // of a later strip may tie with an earlier strip's best at a smaller column;
+                        // ties between lanes are settled at the end
+                        const bool inside = (unsigned)j < (unsigned)L;
+                        const bool cand = candAlways | (candOnLastCol & (j == L - 1));
+                        const bool improves = (h > best) | ((h == best) & (j < bj));
+                        const bool take = inside & cand & improves;
+                        best = take ? h : best;
+                        bi = take ? i : bi;
+                        bj = take ? j : bj;
+                        if (writer & inside) bout[j] = make_int2(h, f);
+                        scCur = scNext;
+                        if constexpr (kStop) {
+                            // First maximum of the column-major scan = the first column holding the
+                            // (known) optimum: once a lane meets it in column c, only the steps that
+                            // complete columns <= c can still change the answer.
+                            const bool hit = take & (h == stopScore);
+                            if (__builtin_amdgcn_ballot_w64(hit)) {
+                                int c = hit ? j : INT32_MAX;
+#pragma unroll
+                                for (int off = 32; off > 0; off >>= 1) c = min(c, __shfl_xor(c, off));
+                                kLimit = min(kLimit, __builtin_amdgcn_readfirstlane(c) + rows);
+                            }
+                            if (k + 1 >= kLimit) break;
+                        }
                     }
+                };
+                if (s == 0) {
+                    if (stopEnabled) steps(std::true_type{}, std::true_type{});
+                    else steps(std::true_type{}, std::false_type{});
+                } else {
+                    steps(std::false_type{}, std::false_type{});   // (the stop rule is for pairs of one strip)
                 }
             }
             if (!lastStrip) __threadfence();
@@ -264,6 +279,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
     }
     if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
     const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
+    const int hFloor = floor0 ? 0 : INT32_MIN;
     const int region = (job.rules >> 4) & 3;
     const int open = a.gapOpen, ext = a.gapExt;
     const uint8_t* tptr = a.residues + job.tOff;
@@ -326,47 +342,53 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
             }
         }
         const int kEnd = min(k0 + kLanes, kLimit);
-        for (int k = k0; k < kEnd; ++k) {
-            const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
-            tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
-            const int scNext = srow[tnext];
-            tres = tnext;
-            int hTop = bH, fTop = bF;
-            if (s == 0) {
-                hTop = topGap ? -min(topOne, topMany) : 0;
-                fTop = kNegInf;
-                topOne += ext;
-                topMany += open;
-            } else {
-                bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
-                bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
+        // (compiled per kind of strip, mask arithmetic for the candidates: see intraseq_kernel)
+        auto steps = [&](auto firstC) {
+            constexpr bool kFirst = decltype(firstC)::value;
+            for (int k = k0; k < kEnd; ++k) {
+                const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
+                tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
+                const int scNext = srow[tnext];
+                tres = tnext;
+                int hTop = bH, fTop = bF;
+                if constexpr (kFirst) {
+                    hTop = topGap ? -min(topOne, topMany) : 0;
+                    fTop = kNegInf;
+                    topOne += ext;
+                    topMany += open;
+                } else {
+                    bH = __builtin_amdgcn_update_dpp(bH, bH, kRol1, 0xf, 0xf, false);
+                    bF = __builtin_amdgcn_update_dpp(bF, bF, kRol1, 0xf, 0xf, false);
+                }
+                const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
+                const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
+                const int j = k - lane;
+                const int eOpen = hLeft - open, eExt = eLeft - ext;
+                const int fOpen = hUp - open, fExt = fUp - ext;
+                const int e = max(eOpen, eExt);
+                const int f = max(fOpen, fExt);
+                const int d = hDiag + scCur;
+                const int h = max(max(d, hFloor), max(e, f));
+                const bool started = j >= 0;
+                hDiag = hUp;
+                hLeft = started ? h : hLeft;
+                eLeft = started ? e : eLeft;
+                fCur = started ? f : fCur;
+                const bool inside = (unsigned)j < (unsigned)L;
+                const bool cand = candAlways | (candOnLastCol & (j == L - 1));
+                const bool improves = (h > best) | ((h == best) & (j < bj));
+                const bool take = inside & cand & improves;
+                best = take ? h : best;
+                bi = take ? i : bi;
+                bj = take ? j : bj;
+                if (writer & inside)
+                    __hip_atomic_store(bout + j, ((unsigned long long)(uint32_t)f << 32) | (uint32_t)h, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                scCur = scNext;
             }
-            const int hUp = __builtin_amdgcn_update_dpp(hTop, hLeft, kShr1, 0xf, 0xf, false);
-            const int fUp = __builtin_amdgcn_update_dpp(fTop, fCur, kShr1, 0xf, 0xf, false);
-            const int j = k - lane;
-            const int eOpen = hLeft - open, eExt = eLeft - ext;
-            const int fOpen = hUp - open, fExt = fUp - ext;
-            const int e = max(eOpen, eExt);
-            const int f = max(fOpen, fExt);
-            const int d = hDiag + scCur;
-            int h = max(d, max(e, f));
-            if (floor0) h = max(h, 0);
-            const bool started = j >= 0;
-            hDiag = hUp;
-            hLeft = started ? h : hLeft;
-            eLeft = started ? e : eLeft;
-            fCur = started ? f : fCur;
-            const bool inside = (unsigned)j < (unsigned)L;
-            const bool take = inside && (candAlways || (candOnLastCol && j == L - 1)) &&
-                              (h > best || (h == best && j < bj));
-            best = take ? h : best;
-            bi = take ? i : bi;
-            bj = take ? j : bj;
-            if (writer && inside)
-                __hip_atomic_store(bout + j, ((unsigned long long)(uint32_t)f << 32) | (uint32_t)h, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            scCur = scNext;
-        }
+        };
+        if (s == 0) steps(std::true_type{});
+        else steps(std::false_type{});
         if (!lastStrip) {
             // columns written so far by lane 63: j = k - 63 for the steps done
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
