@@ -41,3 +41,24 @@ for name, lengths, Q, iters, mode in cases:
     print(f"{name}: {iters} runs, {bad} with differences, {(time.perf_counter() - t0) / iters * 1e3:.2f} ms per search", flush=True)
     db.close()
     assert bad == 0
+
+# ---- the int32 kernel with a pair's strips side by side (intraseq_strips_kernel): the reference's 35 long
+# targets against a 2000-residue query, every mode, against the strip-after-strip kernel's answer
+os.environ.pop("MIOPAL_PAIR_STRIPS", None)
+res, off = _data.random_db(rng, np.arange(1000, 35001, 1000))
+q = _data.random_protein(rng, 2000)
+db = _capi.DeviceDatabase(res, off, 24)
+for algo in ("nw", "hw", "ov", "sw"):
+    os.environ["MIOPAL_NO_PAIR_STRIP_UNITS"] = "1"
+    want = db.search(q, m, 3, 1, "end", algo)
+    os.environ.pop("MIOPAL_NO_PAIR_STRIP_UNITS")
+    bad = 0
+    t0 = time.perf_counter()
+    for k in range(ITER):
+        got = db.search(q, m, 3, 1, "end", algo)
+        if not all(np.array_equal(got[key], want[key]) for key in want):
+            bad += 1
+            print(f"  tail {algo}: run {k} differs", flush=True)
+    print(f"35 tail targets x Q=2000, {algo} end: {ITER} runs, {bad} with differences, {(time.perf_counter() - t0) / ITER * 1e3:.2f} ms per search", flush=True)
+    assert bad == 0
+db.close()
