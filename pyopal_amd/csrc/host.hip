@@ -2519,22 +2519,34 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                 pt.mark("device pipeline + small D2H");
                 if (total < 0 || total > n * slotOps) return fail(MIOPAL_ERR_INTERNAL, "bad operation count");
                 if (!outOps->resize((size_t)total)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+                std::thread copier;
                 if (overlapOps) {
-                    // already in pinned memory (finishDownloads above waited for the side stream too)
+                    // already in pinned memory (finishDownloads above waited for the side stream too): copied
+                    // out by helper threads while this one turns lengths into offsets and checks the scores
                     if (opsFetched != total) return fail(MIOPAL_ERR_INTERNAL, "operation count changed");
-                    Workspace::copyOut(outOps->data, (const char*)ws->pinned + opsBase, (size_t)total);
+                    uint8_t* const dst = outOps->data;
+                    const char* const src = (const char*)ws->pinned + opsBase;
+                    copier = std::thread([dst, src, total] { Workspace::copyOut(dst, src, (size_t)total); });
                 } else {
                     RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
                 }
+                struct Joiner {
+                    std::thread& t;
+                    ~Joiner() { if (t.joinable()) t.join(); }
+                } joinCopier{copier};
                 outOff[0] = 0;
-                for (int64_t k = 0; k < n; ++k) outOff[k + 1] = outOff[k] + lens[(size_t)k];
+                int64_t wrongAt = -1;
+                for (int64_t k = 0; k < n; ++k) {
+                    outOff[k + 1] = outOff[k] + lens[(size_t)k];
+                    if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k] && wrongAt < 0) wrongAt = k;
+                }
                 if (outOff[n] != total) return fail(MIOPAL_ERR_INTERNAL, "operation offsets disagree with the device");
+                if (copier.joinable()) copier.join();
                 RC_TRY(ws->finishDownloads());
                 pt.mark("operations D2H");
-                for (int64_t k = 0; k < n; ++k)
-                    if (endQuery[k] >= 0 && endTarget[k] >= 0 && tscore[(size_t)k] != score[k])
-                        return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
-                                    tscore[(size_t)k], score[k], (long long)(start + k));
+                if (wrongAt >= 0)
+                    return fail(MIOPAL_ERR_INTERNAL, "traceback score %d differs from search score %d for target %lld",
+                                tscore[(size_t)wrongAt], score[wrongAt], (long long)(start + wrongAt));
                 if (!flat) {
                     for (int64_t k = 0; k < n; ++k) {
                         const int64_t len = outOff[k + 1] - outOff[k];
