@@ -432,6 +432,43 @@ def extras(db, query, matrix, Q, N, L):
     out["lognormal_lengths"] = {"targets": int(n), "mean_length": round(float(lengths.mean()), 1),
                                 "max_length": int(lengths.max()),
                                 "host_results_gcups": round(float(Q) * float(lengths.sum()) / dt / 1e9, 1)}
+    del res, off
+    # longer queries on the headline database (the pair-table kernel strip by strip): scores and end locations
+    rng = np.random.default_rng(11)
+    longer = {}
+    for qlen in (150, 300):
+        q = _data.random_protein(rng, qlen)
+        row = {}
+        for mode in ("score", "end"):
+            for _ in range(2):
+                db.search(q, matrix, 3, 1, mode, "sw")
+            t0 = time.perf_counter()
+            for _ in range(5):
+                db.search(q, matrix, 3, 1, mode, "sw")
+            dt = (time.perf_counter() - t0) / 5
+            row[mode] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(float(qlen) * N * L / dt / 1e9, 1)}
+        longer[f"q{qlen}"] = row
+    out["longer_queries_sw"] = longer
+    # BASELINE configs[3] as written: 2000-aa query vs 100k x 2000 PLUS the reference's 35 long targets
+    # (1000 ... 35000 residues: the ones that really leave 16 bits), every algorithm, scores
+    if (N, L) == (1_000_000, 300):
+        rng = np.random.default_rng(2)
+        lengths = np.concatenate([np.full(100_000, 2000), np.arange(1000, 35001, 1000)])
+        res, off = _data.random_db(rng, lengths)
+        q = _data.random_protein(rng, 2000)
+        cdb = _capi.DeviceDatabase(res, off, 24, device=db.device)
+        cells = 2000.0 * float(off[-1])
+        cfg4 = {}
+        for algo in ("nw", "hw", "ov", "sw"):
+            cdb.search(q, matrix, 3, 1, "score", algo)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                cdb.search(q, matrix, 3, 1, "score", algo)
+            dt = (time.perf_counter() - t0) / 2
+            cfg4[algo] = {"ms": round(dt * 1e3, 1), "host_results_gcups": round(cells / dt / 1e9, 1),
+                          "targets_on_the_int32_kernel": int(_capi.DeviceDatabase.last_routing()[0])}
+        cdb.close()
+        out["cfg4_with_tail"] = cfg4
     return out
 
 
