@@ -1621,7 +1621,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                     shift = 0;
                 }
                 if constexpr (kToBelow) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // every row store of the chunk has completed
+                    // every row store of the chunk has COMPLETED before the counter moves: a workgroup-scope
+                    // fence orders but does not wait for them (the same pair of lines in intraseq_strips_kernel
+                    // let a counter overtake its rows under load)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_store(progOut, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }

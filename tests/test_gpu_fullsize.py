@@ -185,3 +185,25 @@ def test_cfg5_whole_database_on_one_gpu(capi):
         np.testing.assert_array_equal(part, gpu[5_000_000:6_000_000])
     finally:
         db.close()
+
+
+def test_long_pairs_beside_the_packed_kernel_repeatedly(capi, monkeypatch):
+    # The int32 kernel's (pair, strip) units run on the side stream BESIDE the packed launch, their rows
+    # crossing XCDs behind progress counters. A counter once overtook its rows under exactly this load (one
+    # wrong score in twenty searches of configs[3] with its tail): every mode, twelve searches each, against
+    # the strip-after-strip kernel's answer - which test_cfg4_every_score_all_modes holds to the CPU checkers.
+    rng = np.random.default_rng(12)
+    lengths = np.concatenate([np.full(20_000, 2000), np.arange(1000, 35001, 1000)])
+    res, off = _data.random_db(rng, lengths)
+    q = _data.random_protein(rng, 2000)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for algo in ("nw", "hw", "ov", "sw"):
+            monkeypatch.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
+            want = db.search(q, B62, 3, 1, "score", algo)["score"]
+            monkeypatch.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
+            for run in range(12):
+                got = db.search(q, B62, 3, 1, "score", algo)["score"]
+                np.testing.assert_array_equal(got, want, err_msg=f"{algo}, search {run}")
+    finally:
+        db.close()

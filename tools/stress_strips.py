@@ -62,3 +62,24 @@ for algo in ("nw", "hw", "ov", "sw"):
     print(f"35 tail targets x Q=2000, {algo} end: {ITER} runs, {bad} with differences, {(time.perf_counter() - t0) / ITER * 1e3:.2f} ms per search", flush=True)
     assert bad == 0
 db.close()
+
+# ---- the same strip units BESIDE the packed kernel (side stream), where a progress counter once overtook its
+# rows: BASELINE configs[3] with its tail, every mode, against the strip-after-strip kernel's answer
+lengths = np.concatenate([np.full(100_000, 2000), np.arange(1000, 35001, 1000)])
+res, off = _data.random_db(rng, lengths)
+q = _data.random_protein(rng, 2000)
+db = _capi.DeviceDatabase(res, off, 24)
+for algo in ("nw", "hw", "ov", "sw"):
+    os.environ["MIOPAL_NO_PAIR_STRIP_UNITS"] = "1"
+    want = db.search(q, m, 3, 1, "score", algo)["score"]
+    os.environ.pop("MIOPAL_NO_PAIR_STRIP_UNITS")
+    bad = 0
+    for k in range(ITER):
+        got = db.search(q, m, 3, 1, "score", algo)["score"]
+        d = np.nonzero(got != want)[0]
+        if len(d):
+            bad += 1
+            print(f"  cfg4 with tail, {algo}: run {k}: targets {d[:5]} (lengths {lengths[d[:5]]}) got {got[d[:5]]} want {want[d[:5]]}", flush=True)
+    print(f"cfg4 with its tail, {algo} score: {ITER} runs, {bad} with differences", flush=True)
+    assert bad == 0
+db.close()
