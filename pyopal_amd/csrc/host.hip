@@ -1450,6 +1450,7 @@ struct Search {
             //   every true H, E, F >= -(3*open + (Q + L)*ext)   and   H <= min(Q, L)*maxScore
             const bool sw = mode == OPAL_MODE_SW;
             const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
+            int packedSkip = firstPos;   // first view position whose packed result is scattered
             // one strip + Smith-Waterman scores: the pair-indexed LDS profile saves the v_perm per cell
             const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
             // first rung of the pair-table kernel: biased integer halves (exact below 25600,
@@ -1561,9 +1562,17 @@ struct Search {
                         }
                     }
                 }
-                // the targets that do not fit form a prefix of the view, empty targets (closed
-                // forms of the border) a suffix; both are redone by the int32 kernel
-                for (int k = firstPos; k < firstFit; ++k) jobs.push_back(forwardJob(view->ids[k], rules));
+                // The targets that do not fit form a prefix of the view: they go to the int32 kernel BESIDE
+                // the packed launch, and the scatter starts behind them (their lanes of the packed kernel hold
+                // nothing). Empty targets (closed forms of the border) form a suffix, redone after the scatter.
+                // (windows of a segmented view are merged by key afterwards: there the whole targets are redone after)
+                if (overlap > 0) {
+                    for (int k = firstPos; k < firstFit; ++k) queueWhole(jobs, view->ids[k]);
+                } else {
+                    for (int k = firstPos; k < firstFit; ++k) sideJobs.push_back(forwardJob(view->ids[k], rules));
+                    packedSkip = firstFit;
+                    g_lastRouting[0] = (int64_t)sideJobs.size();
+                }
                 for (int e = view->nPacked - 1; e >= firstFit && dbLen(db, view->ids[e]) == 0; --e)
                     jobs.push_back(forwardJob(view->ids[e], rules));
             }
@@ -1824,7 +1833,7 @@ struct Search {
                 ws->timings.emplace_back(e0, e1);
                 db->lastTimed = ws;
             }
-            const int nScatter = view->nPacked - firstPos;
+            const int nScatter = view->nPacked - packedSkip;
             if (keyed) {
                 // nothing else writes the results of a segmented search before this point: no
                 // target is kept out of the view, no group is skipped (limit >= one window)
@@ -1835,11 +1844,11 @@ struct Search {
                                            mayOverflow ? (int32_t*)ct : nullptr, stream, keyBias));
                 HIP_TRY(launchDecodeKeys((const unsigned long long*)keys, (int)n, d_score, d_endI, d_endJ, stream, keyBias));
             } else {
-                HIP_TRY(launchScatter(ia.score + firstPos, (const uint8_t*)vo + firstPos, view->d_ids + firstPos,
+                HIP_TRY(launchScatter(ia.score + packedSkip, (const uint8_t*)vo + packedSkip, view->d_ids + packedSkip,
                                       nScatter, start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0,
                                       stream));
                 if (locate)
-                    HIP_TRY(launchScatterEnds(ia.endI + firstPos, ia.endJ + firstPos, view->d_ids + firstPos,
+                    HIP_TRY(launchScatterEnds(ia.endI + packedSkip, ia.endJ + packedSkip, view->d_ids + packedSkip,
                                               nScatter, start, d_endI, d_endJ, stream));
             }
             if (forked) HIP_TRY(hipStreamWaitEvent(stream, ws->evJoin, 0));
