@@ -14,11 +14,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <ctime>
 #include <list>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <numeric>
 #include <string>
 #include <sys/mman.h>
@@ -197,7 +199,12 @@ struct Workspace {
         std::vector<std::thread> pool;
         for (int t = 1; t < nThreads; ++t) {
             const size_t lo = share * t, hi = std::min(bytes, lo + share);
-            if (lo < hi) pool.emplace_back([=] { memcpy((char*)dst + lo, src + lo, hi - lo); });
+            if (lo >= hi) continue;
+            try {
+                pool.emplace_back([=] { memcpy((char*)dst + lo, src + lo, hi - lo); });
+            } catch (const std::exception&) {   // no thread to be had: this one copies the share
+                memcpy((char*)dst + lo, src + lo, hi - lo);
+            }
         }
         memcpy(dst, src, std::min(bytes, share));
         for (auto& th : pool) th.join();
@@ -708,9 +715,18 @@ int streamedUpload(int device, void* deviceDst, size_t bytes, const Fill& fill, 
     if (nThreads == 1) {
         work();
     } else {
+        // (a thread that cannot be started is no error: the pieces are handed out by a counter, whoever
+        // runs takes them - in the last resort this thread alone)
         std::vector<std::thread> pool;
         pool.reserve((size_t)nThreads);
-        for (int t = 0; t < nThreads; ++t) pool.emplace_back(work);
+        for (int t = 1; t < nThreads; ++t) {
+            try {
+                pool.emplace_back(work);
+            } catch (const std::exception&) {
+                break;
+            }
+        }
+        work();
         for (auto& t : pool) t.join();
     }
     for (int k = 0; k < nStreams; ++k)
@@ -784,11 +800,30 @@ void parallelSlices(int nSlices, const Body& body) {
         body(0);
         return;
     }
+    // (what a slice throws - std::bad_alloc - is carried back to the caller once every thread has ended)
+    std::vector<std::exception_ptr> thrown((size_t)nSlices);
+    auto run = [&body, &thrown](int t) {
+        try {
+            body(t);
+        } catch (...) {
+            thrown[(size_t)t] = std::current_exception();
+        }
+    };
     std::vector<std::thread> pool;
     pool.reserve((size_t)nSlices - 1);
-    for (int t = 1; t < nSlices; ++t) pool.emplace_back([&body, t] { body(t); });
-    body(0);
+    int started = 1;   // slices [1, started) have a thread of their own
+    for (; started < nSlices; ++started) {
+        try {
+            pool.emplace_back(run, started);
+        } catch (const std::exception&) {
+            break;
+        }
+    }
+    run(0);
+    for (int t = started; t < nSlices; ++t) run(t);   // (no thread to be had for these)
     for (auto& th : pool) th.join();
+    for (const auto& e : thrown)
+        if (e) std::rethrow_exception(e);
 }
 
 // A device block for a view: one left behind by the views of the handle's previous filling when it
@@ -2029,6 +2064,23 @@ int64_t handleDeviceBytes(MiopalDb* db) {
     return t;
 }
 
+
+// No C++ exception leaves the C ABI (the callers are C, Cython with the GIL released, ctypes): whatever
+// the host code throws - in practice std::bad_alloc from a container of a million entries - becomes
+// MIOPAL_ERR_INTERNAL with the reason in miopalLastError().
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(MIOPAL_ERR_INTERNAL, "unexpected exception: %s", e.what());
+    } catch (...) {
+        return fail(MIOPAL_ERR_INTERNAL, "unexpected exception");
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -2051,6 +2103,7 @@ const char* miopalLastError(void) { return g_lastError.c_str(); }
 
 int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const int* lengths,
                    int64_t count, int alphabetLength, int device) {
+    return guarded([&]() -> int {
     if (!out || count < 0 || (count > 0 && (!sequences || !lengths)))
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to miopalDbCreate");
     if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
@@ -2066,10 +2119,12 @@ int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const 
     ResidueSource src;
     src.sequences = sequences;
     return createCommon(out, src, std::move(offsets), count, alphabetLength, device);
+    });
 }
 
 int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int64_t* offsets,
                        int64_t count, int alphabetLength, int device) {
+    return guarded([&]() -> int {
     if (!out || count < 0 || !offsets) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to miopalDbCreateFlat");
     if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d not in 1..32", alphabetLength);
@@ -2083,6 +2138,7 @@ int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int6
     ResidueSource src;
     src.flat = residues;
     return createCommon(out, src, std::move(off), count, alphabetLength, device);
+    });
 }
 
 void miopalDbDestroy(MiopalDb* db) { delete db; }
@@ -2151,6 +2207,7 @@ int miopalLastKernelTime(MiopalDb* db, float* ms) {
 int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
                              int gapExt, const int* scoreMatrix, int alphabetLength, int mode,
                              int64_t start, int64_t end, int* deviceScores, void* stream) {
+    return guarded([&]() -> int {
     RC_TRY(validate(db, query, queryLength, scoreMatrix, alphabetLength, OPAL_SEARCH_SCORE, mode, start, end));
     if (end == start) return 0;
     if (!deviceScores) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null device score buffer");
@@ -2161,6 +2218,7 @@ int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int query
              OPAL_SEARCH_SCORE, mode, scoreMatrix, start, end, end - start};
     RC_TRY(s.prepare());
     return s.scorePass((int32_t*)deviceScores, nullptr, nullptr);
+    });
 }
 
 static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
@@ -2535,7 +2593,11 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
                     if (opsFetched != total) return fail(MIOPAL_ERR_INTERNAL, "operation count changed");
                     uint8_t* const dst = outOps->data;
                     const char* const src = (const char*)ws->pinned + opsBase;
-                    copier = std::thread([dst, src, total] { Workspace::copyOut(dst, src, (size_t)total); });
+                    try {
+                        copier = std::thread([dst, src, total] { Workspace::copyOut(dst, src, (size_t)total); });
+                    } catch (const std::exception&) {
+                        Workspace::copyOut(dst, src, (size_t)total);
+                    }
                 } else {
                     RC_TRY(ws->stageDownload(outOps->data, pcompact, (size_t)total));
                 }
@@ -2742,15 +2804,18 @@ int miopalSearch(MiopalDb* db, const unsigned char* query, int queryLength, int 
                  const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
                  int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
                  int* startQuery, unsigned char** alignment, int* alignmentLength) {
+    return guarded([&]() -> int {
     return searchImpl(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType, mode,
                       start, end, score, endTarget, endQuery, startTarget, startQuery, alignment,
                       alignmentLength, nullptr, nullptr);
+    });
 }
 
 int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
                      const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
                      int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
                      int* startQuery, unsigned char** operations, int64_t* operationOffsets) {
+    return guarded([&]() -> int {
     HostBytes ops;
     const bool full = searchType == OPAL_SEARCH_ALIGNMENT;
     if (full && !operations) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
@@ -2763,12 +2828,14 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
         *operations = ops.release();
     }
     return 0;
+    });
 }
 
 int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
                         int gapExt, const int* scoreMatrix, int alphabetLength,
                         OpalSearchResult* results[], int searchType, int mode, int overflowMethod,
                         int64_t start, int64_t end) {
+    return guarded([&]() -> int {
     (void)overflowMethod;
     if (!db) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null database handle");
     if (end > db->count) end = db->count;
@@ -2810,6 +2877,7 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
     });
     pt.mark("result structs");
     return 0;
+    });
 }
 
 // ---- opal.h ---------------------------------------------------------------
@@ -2833,6 +2901,7 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
                        int dbSeqLengths[], int gapOpen, int gapExt, int* scoreMatrix,
                        int alphabetLength, OpalSearchResult* results[], const int searchType, int mode,
                        int overflowMethod) {
+    return guarded([&]() -> int {
     if (dbLength <= 0) return 0;
     int device = 0;
     if (const char* env = getenv("MIOPAL_DEVICE")) device = atoi(env);
@@ -2887,6 +2956,7 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
                 ms(t0, t1), ms(t1, t2), ms(t2, std::chrono::steady_clock::now()));
     }
     return rc;
+    });
 }
 
 int opalSearchDatabaseCharSW(unsigned char query[], int queryLength, unsigned char** db, int dbLength,
