@@ -1620,8 +1620,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                     fl -= d;
                     shift = 0;
                 }
-                if constexpr (kToBelow) {
-                    // every row store of the chunk has COMPLETED before the counter moves: a workgroup-scope
+                // (every fourth chunk and the last: the wait below also waits for the loads in flight)
+                if (kToBelow && (((c + 1) & 3) == 0 || c + 1 == nChunks)) {
+                    // every row store of the chunks has COMPLETED before the counter moves: a workgroup-scope
                     // fence orders but does not wait for them (the same pair of lines in intraseq_strips_kernel
                     // let a counter overtake its rows under load)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
