@@ -43,4 +43,4 @@ for Q in QS:
     cells = float(Q) * float(off[-1])
     print(f"Q={Q:5d} {N}x{L}: strips {ta*1e3:8.2f} ms, kernel {ka:8.3f} ms {cells/ka/1e9:6.2f} TCUPS (code {ra[1]}, redone {ra[3]}) | "
           f"general {tb*1e3:8.2f} ms, kernel {kb:8.3f} ms {cells/kb/1e9:6.2f} TCUPS (code {rb[1]}) | equal {same}", flush=True)
-    assert same or os.environ.get('MIOPAL_STRIPS_DEBUG')
+    assert same
