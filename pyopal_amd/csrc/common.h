@@ -48,6 +48,8 @@ struct InterseqArgs {
     int scoreBias;             // ArithSwU16: K, added to every profile entry and taken off the stored H
     int biasedLimit;           // biased flavours: a best at or above this (true score) is flagged
     int biasedZero;            // global biased kernel: pattern of a true 0 at shift 0 (covers the values below 0)
+    int capGroups, capChunks;  // general kernel: the first capGroups groups of the launch sweep at most capChunks chunks
+                               // (their longest targets are computed elsewhere: host.hip, lanes that do not fit)
     int tailThrottle;          // > 0: groups are of similar length; groups per SIMD, rounded up (interseq_impl.h)
     unsigned long long* stripKeys;   // strips kernel with end locations: (score, column, row) keys, view order, zeroed
     int* stripAbort;           // strips kernel: lanes flagged so far (first flags only); at stripAbortAt the launch gives up:

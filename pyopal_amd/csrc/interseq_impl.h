@@ -376,7 +376,8 @@ next_unit:
 
     uint4* prof = ldsProf[wave];
     const uint2* pack = a.pack + a.groupOff[g];
-    const int nChunks = a.groupChunks[g];
+    // (a leading group whose longest targets were handed to the int32 kernel stops at the longest that stays)
+    const int nChunks = groupIndex < a.capGroups ? min(a.groupChunks[g], a.capChunks) : a.groupChunks[g];
     if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);  // long group: critical path
     else if (unitMode) __builtin_amdgcn_s_setprio(0);
     const Arith ar = makeArith<Arith>(a);
