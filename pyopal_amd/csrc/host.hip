@@ -1487,6 +1487,25 @@ struct Search {
             const bool locate = searchType != OPAL_SEARCH_SCORE;  // end locations wanted
             int packedSkip = firstPos;   // first view position whose packed result is scattered
             int capGroups = 0, capChunks = 0;
+            // Smith-Waterman with several strips and no windows (long queries): a few targets far longer
+            // than the rest of the first group set that group's - on the strips kernel the launch's - length
+            // (cfg4 with its tail: 4000 .. 8000 residues among 2000-residue targets, 56 instead of 47 ms).
+            // With a pair's strips side by side the int32 kernel takes them in a few milliseconds beside the
+            // packed launch: up to 64 leading targets more than a quarter longer than the longest of the next
+            // group go there, and the first group stops at the longest target that stays.
+            if (sw && overlap == 0 && Q > kLanes && view->nPacked - firstPos > 2 * kGroupTargets &&
+                !getenv("MIOPAL_NO_SIDE_STREAM") && !getenv("MIOPAL_NO_SKIM")) {
+                const int ref = dbLen(db, view->ids[firstPos + kGroupTargets]);
+                int k = 0;
+                while (k < 64 && (int64_t)dbLen(db, view->ids[firstPos + k]) * 4 > (int64_t)ref * 5 + 1024) ++k;
+                if (k > 0) {
+                    for (int x = 0; x < k; ++x) sideJobs.push_back(forwardJob(view->ids[firstPos + x], rules));
+                    g_lastRouting[0] = (int64_t)sideJobs.size();
+                    packedSkip = firstPos + k;
+                    capGroups = 1;
+                    capChunks = std::max(1, (dbLen(db, view->ids[firstPos + k]) + 3) / 4);
+                }
+            }
             // one strip + Smith-Waterman scores: the pair-indexed LDS profile saves the v_perm per cell
             const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
             // first rung of the pair-table kernel: biased integer halves (exact below 25600,
@@ -1915,7 +1934,7 @@ struct Search {
                     std::vector<uint8_t> flags((size_t)view->nPacked);
                     RC_TRY(ws->stageDownload(flags.data(), vo, flags.size()));
                     RC_TRY(ws->finishDownloads());
-                    for (int k = firstPos; k < view->nPacked; ++k)
+                    for (int k = packedSkip; k < view->nPacked; ++k)
                         if (flags[k]) queueWhole(jobs, view->ids[k]);
                     g_lastRouting[3] = count;
                 }

@@ -1450,7 +1450,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         if (wave >= perBatch || gIdx >= a.nGroups) continue;
         const int g = gIdx + a.groupBase;
         const uint2* pack = a.pack + a.groupOff[g];
-        const int nChunks = a.groupChunks[g];
+        // (a leading group whose longest targets were handed to the int32 kernel stops at the longest that stays)
+        const int nChunks = gIdx < a.capGroups ? min(a.groupChunks[g], a.capChunks) : a.groupChunks[g];
         // (a long group is the launch's critical path: it wins the SIMD's issue arbitration)
         if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
