@@ -56,3 +56,35 @@ def test_fails_loudly_without_device(capi):
     assert capi.lib().miopalDeviceCount() == 0
     with pytest.raises(RuntimeError, match="no supported SIMD backend"):
         capi.DeviceDatabase(np.zeros(4, dtype=np.uint8), np.array([0, 4], dtype=np.int64), 24)
+
+
+def test_reference_entry_point_without_device(capi):
+    """opalSearchDatabase exactly as the reference binds it (src/pyopal/opal.pxd:38-52): argument errors are
+    reported before anything touches a device, an empty database is answered at once (the reference
+    returns 0 for it), and without a GPU the call fails with the reference's own "no SIMD support" code -
+    never with a CPU fallback. The caches it keeps between calls can be dropped at any time."""
+    import torch
+    lib = capi.lib()
+    q = np.array([0, 1, 2, 3], dtype=np.uint8)
+    m = np.ones(24 * 24, dtype=np.int32)
+    seq = np.array([1, 2, 3, 4, 5], dtype=np.uint8)
+    ptrs = np.array([seq.ctypes.data], dtype=np.uint64)
+    lens = np.array([5], dtype=np.int32)
+    res = capi.OpalSearchResult()
+    lib.opalInitSearchResult(ctypes.byref(res))
+    rptr = (ctypes.POINTER(capi.OpalSearchResult) * 1)(ctypes.pointer(res))
+
+    def call(db_length, alphabet=24, lengths=lens):
+        return lib.opalSearchDatabase(q.ctypes.data, len(q), ptrs.ctypes.data, db_length, lengths.ctypes.data, 3, 1,
+                                      m.ctypes.data, alphabet, ctypes.cast(rptr, ctypes.c_void_p), 0, 3, 1)
+
+    assert call(0) == 0                                   # nothing to search
+    assert call(1, alphabet=0) == 101                     # MIOPAL_ERR_BAD_ARGUMENT
+    assert "alphabet length" in capi.last_error()
+    assert call(1, lengths=np.array([-1], dtype=np.int32)) == 101
+    assert "negative sequence length" in capi.last_error()
+    lib.miopalReleaseCaches()                             # (nothing kept: a no-op)
+    if not torch.cuda.is_available():
+        assert call(1) == capi.OPAL_ERR_NO_SIMD_SUPPORT
+        assert res.scoreSet == 0                          # no result was made up
+        lib.miopalReleaseCaches()
