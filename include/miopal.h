@@ -104,7 +104,11 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
  * device pointer with end - start entries (database order), `stream` a
  * hipStream_t (NULL = the null stream). The call only enqueues work; the
  * scores are valid once `stream` has drained. Targets whose 16-bit lanes
- * saturate are recomputed at 32 bit inside the same stream.
+ * saturate are recomputed at 32 bit inside the same stream. (Two kinds of
+ * search synchronise before they return: one whose lanes may leave the
+ * exact range - a 4-byte count comes back - and one that sent long pairs of
+ * a multi-strip query to the wavefront-per-pair kernel's strip units, whose
+ * give-up counter is read so that a partial answer cannot pass for a score.)
  */
 int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int queryLength,
                              int gapOpen, int gapExt, const int* scoreMatrix,
@@ -141,6 +145,15 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
                         int gapExt, const int* scoreMatrix, int alphabetLength,
                         OpalSearchResult* results[], int searchType, int mode,
                         int overflowMethod, int64_t start, int64_t end);
+
+/*
+ * Host-side self tests of the scheduler that need no device (test hook; no reference counterpart).
+ *   which = 1  the packed-view cache survives a builder that throws: the placeholder is dropped, the
+ *              call returns MIOPAL_ERR_INTERNAL, waiters are woken and the same slice can be built
+ *              afterwards (a leaked placeholder would block every later search of the slice).
+ * Returns 0 when the property holds, a positive step number otherwise.
+ */
+int miopalSelfTest(int which);
 
 #ifdef __cplusplus
 }

@@ -41,14 +41,20 @@ def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend
 
     devices = max(1, _capi.lib().miopalDeviceCount())
     chunks = min(threads or devices, size or 1)
-    if chunks == 1 and devices == 1:
-        # one search on the calling thread
+    if size == 0 or (chunks == 1 and devices == 1):
+        # one search on the calling thread (an empty database yields nothing, however many
+        # GPUs there are: src/pyopal/_align.py:129-141)
         yield from aligner.align(query, targets, **options)
         return
 
-    # one contiguous shard per GPU, balanced by residues
+    # one contiguous shard per GPU, balanced by residues. The bounds describe the database as it
+    # is now: a search that finds it mutated since (its own read lock is taken later) falls back
+    # to the whole-database mirror of its device instead of a shard that no longer exists.
+    version = None
     if devices > 1:
         with targets.lock.read:
+            version = getattr(targets, "_version", None)
+            size = targets._get_size()
             lengths = np.fromiter(targets._get_lengths(), dtype=np.int64)[:size]
         offsets = np.zeros(size + 1, dtype=np.int64)
         np.cumsum(lengths, out=offsets[1:])
@@ -72,11 +78,12 @@ def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend
     def search(pieces):
         hits = []
         for begin, stop, device, part in pieces:
-            hits.extend(aligner.align(query, targets, start=begin, end=stop, device=device, shard=part, **options))
+            hits.extend(aligner.align(query, targets, start=begin, end=stop, device=device, shard=part,
+                                      shard_version=version, **options))
         return hits
 
     with contextlib.ExitStack() as stack:
-        workers = pool if pool is not None else stack.enter_context(multiprocessing.pool.ThreadPool(len(jobs)))
+        workers = pool if pool is not None else stack.enter_context(multiprocessing.pool.ThreadPool(max(1, len(jobs))))
         results = workers.imap(search, jobs) if ordered else workers.imap_unordered(search, jobs)
         for hits in results:
             yield from hits

@@ -285,6 +285,41 @@ __host__ __device__ inline int borderGap(int k, int open, int ext) {
     return -(int)(one < many ? one : many);
 }
 
+// ---- hand-over of boundary rows between strips that run in different workgroups (often in
+// different XCDs, whose L2 caches do not see each other). Used by interseq_pair_strips_kernel,
+// interseq_pair_global_strips_kernel (interseq_impl.h) and intraseq_strips_kernel (intraseq.hip); the
+// one place where the pair "fence + s_waitcnt" lives, so that the kernels cannot diverge again.
+//
+// The scheme sits OUTSIDE the LLVM AMDGPU memory model (relaxed atomics carry no ordering there); it
+// relies on what the gfx950 ISA does with them (MI355X_MICROARCH.md, "Valid forms"):
+//  * the rows and the progress counter are relaxed AGENT-scope atomics of 4 or 8 bytes: they compile
+//    to global_store / global_load with sc1 - a store that is written through to memory (acknowledged,
+//    i.e. counted down from vmcnt, only once it is past the local L2) and a load that misses the
+//    local L2;
+//  * producer: every wavefront that stored rows waits for its OWN stores to be acknowledged
+//    (s_waitcnt vmcnt(0)) before it moves the counter. The workgroup-scope release fence in front
+//    only keeps the compiler from sinking the stores below; it orders, it does not wait - without the
+//    s_waitcnt a counter was seen before its rows under load (one wrong score in twenty cfg4 runs);
+//  * consumer: the wavefront that polls loads rows only after its poll matched. The poll's value goes
+//    through readfirstlane into a scalar the loop branches on, so the row loads cannot be issued
+//    before the poll's data has returned; memory instructions of one wavefront issue in order, and the
+//    workgroup-scope acquire fence keeps the compiler from hoisting them. No other wavefront reads
+//    rows on the strength of somebody else's poll.
+// A stale row would be a silently wrong score (the time-out path only covers a strip that never
+// arrives): tests/test_gpu_biased.py and tests/test_gpu_fullsize.py keep one strips-against-general
+// comparison each in the GPU tier.
+static __device__ __forceinline__ void stripPublish(int* counter, int value, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-uniform value of the producer's counter; rows may be loaded once it is large enough
+static __device__ __forceinline__ int stripPoll(const int* counter) {
+    const int v = __hip_atomic_load(const_cast<int*>(counter), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the rows are fetched after the counter)
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 inline int packRules(const DpRules& r) {
     return (r.topGap ? 1 : 0) | (r.leftGap ? 2 : 0) | (r.floor0 ? 4 : 0) | (r.region << 4);
 }

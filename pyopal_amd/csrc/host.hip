@@ -64,6 +64,24 @@ int fail(int code, const char* fmt, ...) {
         if (_rc) return _rc;  \
     } while (0)
 
+// The two events around a timed launch: destroyed unless they were handed to the workspace's list
+// (the score pass has early returns between the first record and the hand-over).
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    EventPair() = default;
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+    ~EventPair() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    std::pair<hipEvent_t, hipEvent_t> release() {
+        std::pair<hipEvent_t, hipEvent_t> p(e0, e1);
+        e0 = e1 = nullptr;
+        return p;
+    }
+};
+
 struct PhaseTimer {
     bool on;
     double t0;
@@ -1048,7 +1066,12 @@ void evictViews(MiopalDb* db, size_t budget, size_t keepCount) {
     }
 }
 
-int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
+// `build` fills the view (buildView; the self test of the guard injects its own). Whatever it does -
+// return an error, or throw (its vectors have a million entries and parallelSlices rethrows what its
+// worker threads threw) - the placeholder is gone and its waiters are woken when this returns: a
+// placeholder left behind would block every later search of the same slice forever.
+template <class Build>
+int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, const Build& build) {
     std::unique_lock<std::mutex> lk(db->viewMutex);
     for (;;) {
         auto it = db->views.begin();
@@ -1065,7 +1088,18 @@ int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_p
     db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, true, nullptr});
     lk.unlock();
     std::shared_ptr<View> v;
-    int rc = buildView(db, start, end, overlap, &v);
+    auto guardedBuild = [&]() -> int {
+        try {
+            return build(&v);
+        } catch (const std::bad_alloc&) {
+            return fail(MIOPAL_ERR_INTERNAL, "out of host memory while building a packed view");
+        } catch (const std::exception& e) {
+            return fail(MIOPAL_ERR_INTERNAL, "building a packed view failed: %s", e.what());
+        } catch (...) {
+            return fail(MIOPAL_ERR_INTERNAL, "building a packed view failed");
+        }
+    };
+    int rc = guardedBuild();
     if (rc != 0) {
         // most likely out of device memory: drop every idle view and try once more
         v.reset();
@@ -1073,7 +1107,7 @@ int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_p
         evictViews(db, 0, 1);
         lk.unlock();
         (void)hipGetLastError();
-        rc = buildView(db, start, end, overlap, &v);
+        rc = guardedBuild();
     }
     lk.lock();
     auto mine = db->views.begin();
@@ -1097,6 +1131,11 @@ int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_p
     return 0;
 }
 
+int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
+    return getViewWith(db, start, end, overlap, out,
+                       [&](std::shared_ptr<View>* v) { return buildView(db, start, end, overlap, v); });
+}
+
 // ---- one search ----------------------------------------------------------------
 struct Search {
     MiopalDb* db;
@@ -1114,6 +1153,10 @@ struct Search {
     int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
     int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
+    // a score pass that starts over (refused launch, declined probe) has already put its side jobs on
+    // the side stream: they are not enqueued twice, and the join still waits for them
+    std::vector<int32_t> sideDone;    // result slots computed on the side stream in this search, sorted
+    bool sideForked = false;
 
     uint8_t* d_query = nullptr;
     int32_t* d_matrix = nullptr;
@@ -1215,9 +1258,14 @@ struct Search {
             RC_TRY(ws->get(kPairStripPartial + slotBase, (ints - 1) * sizeof(int4), &pt));
             HIP_TRY(hipMemsetAsync(st, 0, ints * sizeof(int), on));
             if (!d_stripError) {
+                // The counter only ever moves when a unit gives up, and a search that sees it moved
+                // fails and zeroes it again (checkStripError): it is zeroed ONCE, synchronously, when the
+                // workspace allocates it - no memset on whichever of the two streams asks first, which
+                // launches on the other stream would not be ordered after.
+                const bool fresh = ws->cap[kPairStripError] == 0;
                 void* pe;
                 RC_TRY(ws->get(kPairStripError, sizeof(int), &pe));
-                HIP_TRY(hipMemsetAsync(pe, 0, sizeof(int), on));
+                if (fresh) HIP_TRY(hipMemset(pe, 0, sizeof(int)));
                 d_stripError = (int*)pe;
             }
             a.nStrips = jobStrips;
@@ -1265,6 +1313,16 @@ struct Search {
         a.dirs = d_dirs;
         HIP_TRY(launchIntraseq(a, trace, stream));
         return 0;
+    }
+
+    // After the streams have drained: did a (pair, strip) unit of intraseq_strips_kernel give up?
+    // (both entry points that can route pairs there call it; never seen outside the fault-injection test)
+    int checkStripError() {
+        if (stripErrorHost == 0) return 0;
+        const int seen = stripErrorHost;
+        stripErrorHost = 0;
+        HIP_TRY(hipMemset(d_stripError, 0, sizeof(int)));
+        return fail(MIOPAL_ERR_INTERNAL, "%d (pair, strip) units of the wavefront-per-pair kernel gave up waiting for the strip above", seen);
     }
 
     PairJob forwardJob(int64_t id, int rules) const {
@@ -1658,7 +1716,12 @@ struct Search {
             // targets kept out of the packed view (too long for one lane each) are computed by the
             // int32 kernel on a side stream BESIDE the packed kernel; packed targets that need
             // the int32 kernel are redone after it, because both write the same result slots
-            bool forked = false;
+            bool forked = sideForked;
+            if (!sideDone.empty()) {
+                sideJobs.erase(std::remove_if(sideJobs.begin(), sideJobs.end(), [&](const PairJob& j) {
+                                   return std::binary_search(sideDone.begin(), sideDone.end(), j.out);
+                               }), sideJobs.end());
+            }
             if (!sideJobs.empty() && !getenv("MIOPAL_NO_SIDE_STREAM")) {
                 RC_TRY(ws->ensureAux());
                 RC_TRY(ensurePairInputs());
@@ -1666,8 +1729,10 @@ struct Search {
                 HIP_TRY(hipStreamWaitEvent(ws->aux, ws->evFork, 0));
                 RC_TRY(runPairs(sideJobs, false, d_score, d_endI, d_endJ, nullptr, ws->aux, kAuxJobs - kJobs));
                 HIP_TRY(hipEventRecord(ws->evJoin, ws->aux));
+                for (const PairJob& j : sideJobs) sideDone.push_back(j.out);
+                std::sort(sideDone.begin(), sideDone.end());
                 sideJobs.clear();
-                forked = true;
+                forked = sideForked = true;
                 spt.mark("    side jobs enqueued");
             }
             void *pp, *vs, *vo, *ct;
@@ -1774,11 +1839,11 @@ struct Search {
                 ia.unitPartial = (uint2*)up;
             }
             const bool timed = db->profiling.load() != 0;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
+            EventPair ev;
             if (timed) {
-                HIP_TRY(hipEventCreate(&e0));
-                HIP_TRY(hipEventCreate(&e1));
-                HIP_TRY(hipEventRecord(e0, stream));
+                HIP_TRY(hipEventCreate(&ev.e0));
+                HIP_TRY(hipEventCreate(&ev.e1));
+                HIP_TRY(hipEventRecord(ev.e0, stream));
             }
             g_lastRouting[1] = 1 + 32 * (int)flavour;  // general kernel and its lane arithmetic
             if (pairStrips) {
@@ -1892,9 +1957,9 @@ struct Search {
                 HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
             }
             if (timed) {
-                HIP_TRY(hipEventRecord(e1, stream));
+                HIP_TRY(hipEventRecord(ev.e1, stream));
                 std::lock_guard<std::mutex> g(db->timingMutex);
-                ws->timings.emplace_back(e0, e1);
+                ws->timings.emplace_back(ev.release());
                 db->lastTimed = ws;
             }
             const int nScatter = view->nPacked - packedSkip;
@@ -2207,6 +2272,50 @@ void miopalSetProfiling(MiopalDb* db, int enabled) {
     if (db) db->profiling.store(enabled ? 1 : 0);
 }
 
+int miopalSelfTest(int which) {
+    return guarded([&]() -> int {
+        if (which != 1) return -1;
+        // (no device call on the way: the handle is never filled, the builders are injected)
+        std::unique_ptr<MiopalDb> db(new MiopalDb());
+        std::shared_ptr<View> got;
+        int calls = 0;
+        int rc = getViewWith(db.get(), 0, 10, 0, &got, [&](std::shared_ptr<View>*) -> int {
+            ++calls;
+            throw std::bad_alloc();
+        });
+        if (rc != MIOPAL_ERR_INTERNAL) return 1;
+        if (calls != 2) return 2;                  // built, views evicted, built once more
+        if (!db->views.empty()) return 3;          // no placeholder left behind
+        // a thread that waits for the very slice while its builder fails must come back too
+        std::atomic<int> stage{0};
+        int rcWaiter = -1;
+        std::thread first([&] {
+            std::shared_ptr<View> v;
+            (void)getViewWith(db.get(), 0, 10, 0, &v, [&](std::shared_ptr<View>*) -> int {
+                stage.store(1);
+                while (stage.load() < 2) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                std::this_thread::sleep_for(std::chrono::milliseconds(20));   // the waiter is in wait() by now
+                throw std::runtime_error("injected");
+            });
+        });
+        while (stage.load() < 1) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        std::thread waiter([&] {
+            std::shared_ptr<View> v;
+            stage.store(2);
+            rcWaiter = getViewWith(db.get(), 0, 10, 0, &v, [&](std::shared_ptr<View>* out) -> int {
+                out->reset(new View());
+                return 0;
+            });
+        });
+        first.join();
+        waiter.join();
+        if (rcWaiter != 0) return 4;
+        if (db->views.size() != 1 || db->views.front().building) return 5;
+        db->views.clear();
+        return 0;
+    });
+}
+
 void miopalLastRouting(int64_t counts[4]) {
     if (!counts) return;
     for (int k = 0; k < 4; ++k) counts[k] = g_lastRouting[k];
@@ -2246,7 +2355,16 @@ int miopalSearchDeviceScores(MiopalDb* db, const unsigned char* query, int query
     Search s{db, lease.ws, (hipStream_t)stream, query, queryLength, gapOpen, gapExt, alphabetLength,
              OPAL_SEARCH_SCORE, mode, scoreMatrix, start, end, end - start};
     RC_TRY(s.prepare());
-    return s.scorePass((int32_t*)deviceScores, nullptr, nullptr);
+    RC_TRY(s.scorePass((int32_t*)deviceScores, nullptr, nullptr));
+    if (s.d_stripError) {
+        // Long pairs went through the (pair, strip) units of the int32 kernel, whose units can give up
+        // waiting (never seen): the only searches of this entry point that synchronise, so that a
+        // partial answer cannot pass for a score.
+        RC_TRY(lease.ws->stageDownload(&s.stripErrorHost, s.d_stripError, sizeof(int)));
+        RC_TRY(lease.ws->finishDownloads());
+        RC_TRY(s.checkStripError());
+    }
+    return 0;
     });
 }
 
@@ -2292,9 +2410,7 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
     if (s.d_stripError) RC_TRY(ws->stageDownload(&s.stripErrorHost, s.d_stripError, sizeof(int)));
     RC_TRY(ws->finishDownloads());
     HIP_TRY(hipStreamSynchronize(stream));
-    if (s.stripErrorHost != 0)
-        return fail(MIOPAL_ERR_INTERNAL, "%d (pair, strip) units of the wavefront-per-pair kernel gave up waiting for the strip above",
-                    s.stripErrorHost);
+    RC_TRY(s.checkStripError());
     pt.mark("score/end pass + D2H");
     if (searchType != OPAL_SEARCH_ALIGNMENT) return 0;
 

@@ -1480,9 +1480,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             // (wave-uniform: every lane reads the same counter)
             int spins = 0;
             while (avail < need) {
-                const int v = __hip_atomic_load(const_cast<int*>(progIn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the rows are fetched after the counter)
-                avail = __builtin_amdgcn_readfirstlane(v);
+                avail = stripPoll(progIn);
                 if (avail >= need) break;
                 __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
                 if (++spins > kStripSpinCap) avail = kStripPoison;
@@ -1624,12 +1622,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 }
                 // (every fourth chunk and the last: the wait below also waits for the loads in flight)
                 if (kToBelow && (((c + 1) & 3) == 0 || c + 1 == nChunks)) {
-                    // every row store of the chunks has COMPLETED before the counter moves: a workgroup-scope
-                    // fence orders but does not wait for them (the same pair of lines in intraseq_strips_kernel
-                    // let a counter overtake its rows under load)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(progOut, c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // every row store of the chunks has COMPLETED before the counter moves (stripPublish, common.h)
+                    stripPublish(progOut, c + 1, lane);
                 }
             }
         };

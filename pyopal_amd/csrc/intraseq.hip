@@ -319,9 +319,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
                 const int need = min(k0 + kLanes, L);
                 int spins = 0;
                 while (avail < need) {
-                    const int v = __hip_atomic_load(const_cast<int*>(progIn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    avail = __builtin_amdgcn_readfirstlane(v);
+                    avail = stripPoll(progIn);
                     if (avail >= need) break;
                     __builtin_amdgcn_s_sleep(4);
                     if (++spins > kStripWaitCap) {
@@ -391,13 +389,9 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
         else steps(std::false_type{});
         if (!lastStrip) {
             // columns written so far by lane 63: j = k - 63 for the steps done
-            // (a workgroup-scope fence orders, it does not wait for the stores to complete: without the
-            // s_waitcnt the counter was seen before the rows under load - one wrong score in twenty runs
-            // of cfg4 with its tail beside the packed kernel)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (every row store acknowledged before the counter moves: stripPublish, common.h)
             const int done = min(max(kEnd - (kLanes - 1), 0), L);
-            if (lane == 0) __hip_atomic_store(progOut, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            stripPublish(progOut, done, lane);
         }
     }
     if (dead) {

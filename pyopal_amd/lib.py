@@ -545,14 +545,17 @@ class Aligner:
     def align(self, query, database: BaseDatabase, *, mode: str = "score",
               overflow: str = "buckets", algorithm: str = "sw", start: int = 0,
               end: int = UINT32_MAX, device: int = 0,
-              shard: typing.Optional[typing.Tuple[int, int]] = None) -> typing.List[ScoreResult]:
+              shard: typing.Optional[typing.Tuple[int, int]] = None,
+              shard_version: typing.Optional[int] = None) -> typing.List[ScoreResult]:
         """Align the query to every target of ``database[start:end]``.
 
         Same keywords as the reference (``src/pyopal/lib.pyx:1258-1268``);
         ``device`` (extension) selects the GPU holding the database mirror, ``shard`` (extension)
         a mirror of the targets ``[lo, hi)`` only, which must contain ``[start, end)``: what
-        `pyopal_amd.align` uses to give every GPU its own part of the database. Target indices
-        of the results are absolute either way.
+        `pyopal_amd.align` uses to give every GPU its own part of the database; with
+        ``shard_version`` the shard only counts while the database is still in the state it was cut
+        in (a database mutated since is searched through the whole-database mirror of ``device``).
+        Target indices of the results are absolute either way.
         ``overflow`` is validated and otherwise ignored: the GPU path picks the
         narrowest exact lane width per target, results are identical.
         """
@@ -583,6 +586,8 @@ class Aligner:
 
         with database.lock.read:
             size = database._get_size()
+            if shard is not None and shard_version is not None and getattr(database, "_version", None) != shard_version:
+                shard = None
             if end < start:
                 raise IndexError("database slice end is lower than start")
             if end > size:

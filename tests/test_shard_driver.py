@@ -171,3 +171,50 @@ def test_align_shards_the_database_over_devices(monkeypatch):
     # a mutation drops every shard mirror
     db.append("ACDE")
     assert [r.target_index for r in pyopal_amd.align(query, db, threads=2, ordered=True)] == list(range(len(seqs) + 1))
+
+
+def test_align_empty_and_single_target_with_several_devices(monkeypatch):
+    # an empty database yields nothing however many GPUs are visible (src/pyopal/_align.py:129-141:
+    # threads = 1, the aligner returns an empty list), and one target is one chunk on one GPU
+    _FakeDevices(monkeypatch, 2)
+    import pyopal_amd
+    for threads in (0, 1, 2, 5):
+        assert list(pyopal_amd.align("ACDE", pyopal_amd.Database(), threads=threads)) == []
+        assert list(pyopal_amd.align("ACDE", [], threads=threads, ordered=True)) == []
+    one = pyopal_amd.Database(["ACDEFG"])
+    want = pyopal_amd.Aligner().align("ACDE", one, mode="full")
+    for threads in (0, 1, 3):
+        got = list(pyopal_amd.align("ACDE", one, mode="full", threads=threads, ordered=True))
+        assert [(r.target_index, r.score, r.alignment) for r in got] == \
+               [(r.target_index, r.score, r.alignment) for r in want]
+
+
+def test_align_survives_a_mutation_between_sharding_and_search(monkeypatch):
+    # the shard bounds are cut under a read lock that is released before the chunks are searched: a
+    # search that finds the database mutated since uses the whole-database mirror of its device
+    # instead of failing on a shard that no longer exists
+    import numpy as np
+    fake = _FakeDevices(monkeypatch, 2)
+    import pyopal_amd
+    import _data
+    rng = np.random.default_rng(5)
+    seqs = ["".join(_data.NCBI[c] for c in _data.random_protein(rng, int(n))) for n in rng.integers(5, 60, size=40)]
+    db = pyopal_amd.Database(seqs)
+    aligner = pyopal_amd.Aligner()
+    want = [r.score for r in aligner.align("ACDEFGHIKL", db)]
+    stale = db._version
+    db.append("ACDEFGHIKLMN")    # shrinks nothing, but every shard cut before it is void
+    got = aligner.align("ACDEFGHIKL", db, start=10, end=20, device=1, shard=(8, 25), shard_version=stale)
+    assert [r.target_index for r in got] == list(range(10, 20))
+    assert [r.score for r in got] == want[10:20]
+    assert fake.uploads[-1][1] == len(seqs) + 1     # the whole database went to device 1, not the stale shard
+    while len(db) > 5:
+        del db[len(db) - 1]
+    got = aligner.align("ACDEFGHIKL", db, start=2, end=30, device=0, shard=(0, 20), shard_version=stale)
+    assert [r.target_index for r in got] == [2, 3, 4]
+    try:
+        aligner.align("ACDEFGHIKL", db, start=10, end=20, device=0, shard=(8, 25), shard_version=stale)
+    except IndexError:
+        pass
+    else:
+        raise AssertionError("a slice past the end of the shrunken database must raise IndexError")

@@ -44,6 +44,23 @@ if "GRBM_GUI_ACTIVE" in counters:
     summary["effective_clock_ghz"] = counters["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8 / (kernel_ms * 1e-3) / 1e9
 if "SQ_INSTS_VALU" in counters:
     summary["simd_cycles_per_valu_instr_at_2.4GHz"] = kernel_ms * 1e-3 * 2.4e9 * 1024 / counters["SQ_INSTS_VALU"]["mean_per_launch"]
+cells = float(os.environ.get("PMC_CELLS") or 0)
+if cells and "SQ_INSTS_VALU" in counters:
+    # one wave instruction advances 64 lanes x 2 packed targets
+    summary["dp_cells_per_search"] = cells
+    summary["valu_instr_per_lane_cell_pair"] = counters["SQ_INSTS_VALU"]["mean_per_launch"] * 128 / cells
+    summary["simd_cycles_per_lane_cell_pair_at_2.4GHz"] = kernel_ms * 1e-3 * 2.4e9 * 1024 * 128 / cells
+    summary["cells_note"] = ("per launch of the named kernel when one launch covers the whole search "
+                             "(side-stream and probe launches excluded by the kernel name)")
+if "SQ_WAVE_CYCLES" in counters:
+    wc = counters["SQ_WAVE_CYCLES"]["mean_per_launch"]
+    summary["fractions_of_wave_cycles"] = {
+        k: counters[k]["mean_per_launch"] / wc
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                  "SQ_ACTIVE_INST_LDS") if k in counters}
+if "SQ_LDS_IDX_ACTIVE" in counters and "SQ_LDS_BANK_CONFLICT" in counters:
+    summary["lds_bank_conflict_fraction"] = (counters["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] /
+                                             max(counters["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"], 1.0))
 json.dump(summary, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "counters"}, indent=1))
 print({k: round(v["mean_per_launch"]) for k, v in counters.items()})
