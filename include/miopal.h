@@ -130,7 +130,8 @@ int miopalLastKernelTime(MiopalDb* db, float* ms);
  *   counts[0] targets computed by the wavefront-per-pair (int32) kernel
  *   counts[1] kernel of the lane-per-target pass, low four bits: 0 none, 1 general (v_perm profile), 2 / 3 / 4
  *             pair table with int16 / half-float / biased-integer lanes (Smith-Waterman), 5 pair table for
- *             NW / HW / OV, 6 pair table strip by strip (Smith-Waterman scores of several strips); + 16 when the
+ *             NW / HW / OV, 6 pair table strip by strip (Smith-Waterman scores of several strips), 7 the same for
+ *             NW / HW / OV; + 16 when the
  *             pair-table launch was refused and the general kernel ran instead;
  *             + 32 x the general kernel's lane arithmetic (0 half floats, 1 int16, 2 signed int16, 4 / 5
  *             anti-diagonally shifted signed / unsigned, 6 column-shifted unsigned Smith-Waterman)
@@ -154,6 +155,18 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
  * Returns 0 when the property holds, a positive step number otherwise.
  */
 int miopalSelfTest(int which);
+
+/*
+ * Fault injection for the time-out escapes of the strip hand-over (test hook; no reference
+ * counterpart; an argument of the NEXT search of the calling thread, not an environment switch):
+ *   kind 1  unit `unit` of the pair-table strips kernels (Smith-Waterman or NW / HW / OV of several
+ *           strips) publishes nothing: the units below it give up after `spinCap` polls, flag their
+ *           lanes, and the int32 kernel returns the right scores;
+ *   kind 2  unit `unit` of the wavefront-per-pair strips kernel publishes nothing: the search returns
+ *           MIOPAL_ERR_INTERNAL and the handle stays usable.
+ * spinCap = 0 keeps the kernels' own patience (about a second).
+ */
+void miopalTestInjectFault(int kind, int unit, int spinCap);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,8 @@ EXPORTS = [
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalLastRouting", "miopalSearchResults", "miopalReleaseCaches",
+    # test hooks
+    "miopalSelfTest", "miopalTestInjectFault",
 ]
 
 

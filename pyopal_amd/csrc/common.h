@@ -56,6 +56,8 @@ struct InterseqArgs {
     int stripAbortAt;          //   the view is redone by the next rung anyway (it adds the same to *stripGaveUp)
     int* stripGaveUp;          //   = the overflow counter the host reads after the scatter
     int batchGroups;           // strips kernel: groups a workgroup sweeps side by side (1..12; fewer when the groups are few)
+    int stripSpinCap;          // strips kernels: polls (x s_sleep) before a unit gives up on the strip above; 0 = the default
+    int faultUnit1;            // strips kernels, test hook: unit (this - 1) behaves as if it had died; 0 = none
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -103,6 +105,8 @@ struct IntraseqArgs {
     int* stripProgress;       // zeroed, [nJobs x nStrips]: columns of the strip's last row published
     int4* stripPartial;       // [nJobs x nStrips]: (score, row, column) of the strip
     int* error;               // incremented by a unit that gave up waiting (never seen)
+    int stripWaitCap;         // polls before a unit gives up on the strip above; 0 = the default
+    int faultUnit1;           // test hook: unit (this - 1) publishes nothing; 0 = none
 };
 
 struct WalkArgs {
@@ -188,7 +192,8 @@ enum PairFlavour : int {
     kPairSwHalf = 1,    // packed half floats, exact below 2048
     kPairSwBiased = 2,  // biased integer halves compared as half floats, column-shifted (interseq_impl.h)
     kPairGlobalBiased = 3, // NW / HW / OV on the same representation (scores, optional end locations)
-    kPairSwStrips = 4      // Smith-Waterman scores of several strips on biased halves (units of (batch, strip))
+    kPairSwStrips = 4,     // Smith-Waterman scores of several strips on biased halves (units of (batch, strip))
+    kPairGlobalStrips = 5  // NW / HW / OV of several strips on the same units (scores; end locations through keys)
 };
 // limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
 constexpr int kPairStripsMaxRows = 52, kPairStripsMaxRowsLoc = 48;   // tallest strips of the multi-strip pair-table kernel
@@ -212,6 +217,13 @@ hipError_t launchInterseqPairSwStripsA(const InterseqArgs& a, int rows, int comp
 hipError_t launchInterseqPairSwStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalStripsA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalStripsLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+hipError_t launchInterseqPairGlobalStripsLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+// keys of the multi-strip NW / HW / OV kernel -> view-order scores and end locations (endI / endJ may be null)
+hipError_t launchDecodeGlobalKeys(const unsigned long long* keys, const int32_t* lens, int n, int queryLength,
+                                  int32_t* score, int32_t* endI, int32_t* endJ, hipStream_t stream);
 // (score, column, row) keys of the strips kernel -> view-order scores and end locations
 hipError_t launchDecodeStripKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ, hipStream_t stream);
 hipError_t launchInterseqPairGlobalA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

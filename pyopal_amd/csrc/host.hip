@@ -39,6 +39,7 @@ namespace {
 
 thread_local std::string g_lastError;
 thread_local int64_t g_lastRouting[4] = {0, 0, 0, 0};  // miopalLastRouting
+thread_local int g_fault[3] = {0, 0, 0};               // miopalTestInjectFault: kind, unit, spin cap
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -1150,11 +1151,15 @@ struct Search {
     int64_t balancedChunks = 0;
     bool globalPairRefused = false;   // the pair-table launch for NW / HW / OV failed on this device
     bool pairStripsRefused = false;   // the same for the multi-strip Smith-Waterman kernel
+    bool globalStripsRefused = false; // ... and for the multi-strip NW / HW / OV kernel
     int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
     int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
     // a score pass that starts over (refused launch, declined probe) has already put its side jobs on
     // the side stream: they are not enqueued twice, and the join still waits for them
+    // test hook (miopalTestInjectFault): kind 1 = a unit of the pair-table strips kernels, 2 = a unit of
+    // intraseq_strips_kernel publishes nothing; the units below it wait at most faultSpinCap polls
+    int faultKind = 0, faultUnit = 0, faultSpinCap = 0;
     std::vector<int32_t> sideDone;    // result slots computed on the side stream in this search, sorted
     bool sideForked = false;
 
@@ -1172,6 +1177,12 @@ struct Search {
     }
 
     int prepare() {
+        if (g_fault[0] != 0) {   // one search only
+            faultKind = g_fault[0];
+            faultUnit = g_fault[1];
+            faultSpinCap = g_fault[2];
+            g_fault[0] = 0;
+        }
         maxScore = *std::max_element(matrix, matrix + A * A);
         minScore = *std::min_element(matrix, matrix + A * A);
         return 0;
@@ -1273,6 +1284,8 @@ struct Search {
             a.stripProgress = (int*)st + 1;
             a.stripPartial = (int4*)pt;
             a.error = d_stripError;
+            a.stripWaitCap = faultSpinCap;
+            a.faultUnit1 = faultKind == 2 ? faultUnit + 1 : 0;
             HIP_TRY(launchIntraseqStrips(a, on));
             return 0;
         }
@@ -1505,6 +1518,63 @@ struct Search {
                 }
             }
         }
+        // NW / HW / OV of more rows than one pair table holds: the same units with the one-strip global
+        // kernel's cell (interseq_pair_global_strips_kernel, round 3: 3 integer adds + 3 max per cell pair
+        // and no v_perm, against 5 + 1 v_perm and a barrier per chunk on the general kernel's cheapest
+        // lanes). The true values around a pattern's zero are bounded by the QUERY (all of it: the strips
+        // share one scale), not by the targets' lengths, so no target is redone at 32 bit; the bounds are
+        // static:   below zero: 3 open + (Q + 4) ext + |min S|
+        //           above: NW Q (max S + ext), HW / OV Q max S + the rebase shift.
+        // A 2000-residue query under BLOSUM62 3 / 1 (BASELINE configs[3]) fits; from about 2200 (HW / OV)
+        // and 2350 residues (NW) on the general kernel takes over.
+        bool globalStrips = false;
+        if (mode != OPAL_MODE_SW && useHalf && !globalStripsRefused && !getenv("MIOPAL_NO_BIASED") &&
+            !getenv("MIOPAL_NO_GLOBAL_STRIPS") && !getenv("MIOPAL_STRIPS")) {
+            const char* noPair = getenv("MIOPAL_NO_PAIR_TABLE");
+            const int single = std::max(2, (Q + 1) / 2 * 2);
+            const bool oneStrip = Q <= kLanes && interseqPairFits(single, A + 1);
+            // (with end locations the row / column bookkeeping costs registers: shorter strips)
+            int maxRows = searchType != OPAL_SEARCH_SCORE ? kPairStripsMaxRowsLoc : kPairStripsMaxRows;
+            while (maxRows >= 32 && !interseqPairFits(maxRows, A + 1)) maxRows -= 2;
+            const int64_t pos = std::max(maxScore, 0);
+            const int64_t zeroG = 0x0400 + 3 * (int64_t)open + ((int64_t)Q + 4) * ext + std::max(0, -minScore);
+            const int64_t above = r.topGap ? (int64_t)Q * (pos + ext) : (int64_t)Q * pos + kLocMaxShift;
+            const bool inRange = zeroG + above + 5 * (int64_t)ext + pos < 0x7C00 && 5 * (int64_t)ext <= kLocMaxShift &&
+                                 minScore > kBiasedPad && (r.topGap ? open >= ext : true);
+            if (!oneStrip && maxRows >= 32 && Q > 32 && inRange && !(noPair && noPair[0] == '1')) {
+                // strip height: even, at most maxRows; every strip costs about four rows' worth of per-column
+                // work on top of its cells (row above in, last row out, answers), and a last query row that
+                // is the strip's last row is read without a select (Q = 2000: 40 strips of 50 rows)
+                int bestRows = 0, bestNs = 0;
+                int64_t bestCost = 0;
+                for (int rowsP = maxRows; rowsP >= 32; rowsP -= 2) {
+                    const int ns = (Q + rowsP - 1) / rowsP;
+                    if (ns < 2 || (int64_t)(ns - 1) * rowsP >= Q) continue;
+                    const int64_t cost = (int64_t)ns * (rowsP + 4) + ((int64_t)ns * rowsP - Q > 1 ? rowsP / 8 : 0);
+                    if (bestRows == 0 || cost < bestCost) {
+                        bestRows = rowsP;
+                        bestNs = ns;
+                        bestCost = cost;
+                    }
+                }
+                if (bestRows > 0 && bestNs <= 4096) {
+                    const int64_t units = (int64_t)((view->nGroups + 11) / 12) * bestNs;
+                    int64_t totalChunks = 0;
+                    for (int c : view->groupChunksHost) totalChunks += c;
+                    const int64_t balanced = totalChunks * bestNs / ((int64_t)db->computeUnits * 12);
+                    const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= balanced;
+                    // (the same two limits as the Smith-Waterman strips kernel: units enough to keep every
+                    // CU on one strip for a while, the longest group short against the launch)
+                    const bool enough = ((bestNs >= 16 || 2 * units >= 5 * (int64_t)db->computeUnits) && hidden) || getenv("MIOPAL_PAIR_STRIPS");
+                    if (enough) {
+                        stripRows = bestRows;
+                        nStrips = bestNs;
+                        waves = 1;
+                        globalStrips = true;
+                    }
+                }
+            }
+        }
         // A group keeps its wavefronts busy for (columns of its longest target) x (rounds of strips).
         // Groups far above the balanced share of a workgroup slot would stretch the kernel to
         // their own length (one lane per target cannot split a target), so the leading
@@ -1551,7 +1621,7 @@ struct Search {
             // With a pair's strips side by side the int32 kernel takes them in a few milliseconds beside the
             // packed launch: up to 64 leading targets more than a quarter longer than the longest of the next
             // group go there, and the first group stops at the longest target that stays.
-            if (sw && overlap == 0 && Q > kLanes && view->nPacked - firstPos > 2 * kGroupTargets &&
+            if ((sw || globalStrips) && overlap == 0 && Q > kLanes && view->nPacked - firstPos > 2 * kGroupTargets &&
                 !getenv("MIOPAL_NO_SIDE_STREAM") && !getenv("MIOPAL_NO_SKIM")) {
                 const int ref = dbLen(db, view->ids[firstPos + kGroupTargets]);
                 int k = 0;
@@ -1622,7 +1692,7 @@ struct Search {
                 5 * (int64_t)ext <= kLocMaxShift &&
                 globalZero + (int64_t)Q * (std::max(maxScore, 0) + ext) + kLocMaxShift + 5 * (int64_t)ext +
                         std::max(maxScore, 0) < 0x7C00;
-            if (globalPair) {
+            if (globalPair || globalStrips) {
                 // only empty targets (closed forms of the border) are left to the int32 kernel
                 for (int e = view->nPacked - 1; e >= firstPos && dbLen(db, view->ids[e]) == 0; --e)
                     jobs.push_back(forwardJob(view->ids[e], rules));
@@ -1753,7 +1823,11 @@ struct Search {
             }
             const int64_t reach = std::min<int64_t>((int64_t)std::min(Q, view->maxPackedLen) * std::max(maxScore, 0), queryBest);
             const int64_t limit = (biased || pairStrips) ? biasedLimit : swShifted ? swLimit : halfFloat ? 2048 : 32767;
-            const bool mayOverflow = sw && reach >= limit;
+            // (the multi-strip NW / HW / OV kernel flags nothing for its range; the count brings back the
+            // lanes of units that gave up on the strip above - never seen outside the fault-injection test)
+            // (the strips kernels: always - the count also brings back the lanes of a unit that gave up on
+            // the strip above it; searches of several strips take milliseconds, the 4-byte download is free)
+            const bool mayOverflow = sw ? (reach >= limit || pairStrips) : globalStrips;
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
             ia.pack = view->d_pack;
@@ -1780,7 +1854,9 @@ struct Search {
                 ia.endI = (int32_t*)vi;
                 ia.endJ = (int32_t*)vj;
             }
-            ia.overflow = sw ? (uint8_t*)vo : nullptr;
+            ia.overflow = (sw || globalStrips) ? (uint8_t*)vo : nullptr;
+            ia.stripSpinCap = faultSpinCap;
+            ia.faultUnit1 = faultKind == 1 ? faultUnit + 1 : 0;
             ia.biasedLimit = swShifted ? swLimit : biasedLimit;
             ia.scoreBias = swBias;
             ia.biasedZero = (int)globalZero;
@@ -1812,13 +1888,16 @@ struct Search {
                 const size_t ints = (size_t)ia.nGroups * nStrips + 2;
                 RC_TRY(ws->get(kUnitState, ints * sizeof(int), &us));
                 HIP_TRY(hipMemsetAsync(us, 0, ints * sizeof(int), stream));
-                if (mayOverflow) {
+                if (mayOverflow && sw) {
                     // more flagged lanes than are redone one by one: the launch stops, the view takes the next rung
                     ia.stripAbort = (int*)us + ints - 1;
                     ia.stripAbortAt = 2 * kMaxDirectRecompute;
                     ia.stripGaveUp = (int*)ct;
                 }
-                HIP_TRY(hipMemsetAsync(vs, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
+                // (the scores-only form of the NW / HW / OV kernel folds OV's candidates into the view scores,
+                // and what a unit that gave up leaves behind is "minus infinity" in every mode)
+                if (globalStrips) HIP_TRY(launchFillInt32((int32_t*)vs, view->nGroups * kGroupTargets, INT32_MIN, stream));
+                else HIP_TRY(hipMemsetAsync(vs, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
                 HIP_TRY(hipMemsetAsync(vo, 0, (size_t)view->nGroups * kGroupTargets, stream));
                 ia.unitCounter = (int*)us;
                 ia.unitFlags = (int*)us + 1;
@@ -1856,14 +1935,15 @@ struct Search {
                     // runs AFTER the packed kernel (log-normal lengths, NW at Q = 53, 6400 pairs on the side:
                     // 2.07 ms; with CUs kept out of the persistent launch 1.66 ms). One CU per 256 pairs.
                     pairUnits = std::max(1, pairUnits - (int)std::min<int64_t>(pairUnits / 4, std::max<int64_t>(8, (g_lastRouting[0] + 255) / 256)));
-                g_lastRouting[1] = 2 + (int)kPairSwStrips;
+                const PairFlavour stripsFlavour = globalStrips ? kPairGlobalStrips : kPairSwStrips;
+                g_lastRouting[1] = 2 + (int)stripsFlavour;
                 // few (group, strip) units: fewer groups per workgroup, so that every CU gets a unit and a
                 // wavefront shares its SIMD with fewer others
                 ia.batchGroups = (int)std::max<int64_t>(1, std::min<int64_t>(12, (int64_t)ia.nGroups * nStrips / std::max(1, pairUnits)));
                 hipError_t pe = hipSuccess;
                 // (random pairs only get there in the linear regime of the scoring system, and then score
                 // about half a unit per aligned residue: nothing to probe for under ~500 residues)
-                if (locate && mayOverflow && std::min(Q, view->maxPackedLen) >= 512 && !getenv("MIOPAL_PAIR_STRIPS")) {
+                if (sw && locate && mayOverflow && std::min(Q, view->maxPackedLen) >= 512 && !getenv("MIOPAL_PAIR_STRIPS")) {
                     // With end locations a lane is exact below 384 (768 for strips of 32 rows). Scores of
                     // long queries against long targets under cheap gaps are in the thousands - every lane
                     // would be redone, and a launch that gives up half-way has cost half its time. The
@@ -1893,18 +1973,21 @@ struct Search {
                         HIP_TRY(hipMemsetAsync(ia.score, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
                     }
                 }
-                if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, kPairSwStrips, pairUnits, stream, locate);
+                if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, stripsFlavour, pairUnits, stream, locate);
                 if (pe != hipSuccess) {
                     // (e.g. the runtime refuses 150 KB of dynamic LDS: start over on the general kernel)
                     (void)hipGetLastError();
-                    pairStripsRefused = true;
+                    (globalStrips ? globalStripsRefused : pairStripsRefused) = true;
                     if (getenv("MIOPAL_VERBOSE"))
                         fprintf(stderr, "miopal: multi-strip pair-table kernel refused (%s), using the general kernel\n",
                                 hipGetErrorString(pe));
                     return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
                 }
                 // (score, column, row) keys merged over the strips -> view-order scores and end locations
-                if (locate)
+                if (globalStrips && locate)
+                    HIP_TRY(launchDecodeGlobalKeys(ia.stripKeys, view->d_lens, view->nGroups * kGroupTargets, Q, ia.score,
+                                                   ia.endI, ia.endJ, stream));
+                else if (locate)
                     HIP_TRY(launchDecodeStripKeys(ia.stripKeys, view->nGroups * kGroupTargets, ia.score, ia.endI, ia.endJ, stream));
             } else if (usePair || globalPair) {
                 void* wc;
@@ -2272,6 +2355,12 @@ void miopalSetProfiling(MiopalDb* db, int enabled) {
     if (db) db->profiling.store(enabled ? 1 : 0);
 }
 
+void miopalTestInjectFault(int kind, int unit, int spinCap) {
+    g_fault[0] = kind;
+    g_fault[1] = unit;
+    g_fault[2] = spinCap;
+}
+
 int miopalSelfTest(int which) {
     return guarded([&]() -> int {
         if (which != 1) return -1;
@@ -2292,13 +2381,16 @@ int miopalSelfTest(int which) {
         std::thread first([&] {
             std::shared_ptr<View> v;
             (void)getViewWith(db.get(), 0, 10, 0, &v, [&](std::shared_ptr<View>*) -> int {
-                stage.store(1);
-                while (stage.load() < 2) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                // (called twice: a failed build is retried once after the idle views were dropped)
+                int expected = 0;
+                stage.compare_exchange_strong(expected, 1);
+                for (int spins = 0; stage.load() < 2 && spins < 5000; ++spins)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1));
                 std::this_thread::sleep_for(std::chrono::milliseconds(20));   // the waiter is in wait() by now
                 throw std::runtime_error("injected");
             });
         });
-        while (stage.load() < 1) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        for (int spins = 0; stage.load() < 1 && spins < 5000; ++spins) std::this_thread::sleep_for(std::chrono::milliseconds(1));
         std::thread waiter([&] {
             std::shared_ptr<View> v;
             stage.store(2);

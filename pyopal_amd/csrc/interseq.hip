@@ -38,8 +38,9 @@ bool interseqPairFits(int rowsPerStrip, int nSymbols) {
 hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavour flavour, int computeUnits,
                               hipStream_t stream, bool locate) {
     if (a.nGroups <= 0) return hipSuccess;
-    if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased && flavour != kPairSwStrips) return hipErrorInvalidValue;
-    if (a.nStrips != 1 && flavour != kPairSwStrips) return hipErrorInvalidValue;
+    if (locate && flavour != kPairSwBiased && flavour != kPairGlobalBiased && flavour != kPairSwStrips && flavour != kPairGlobalStrips)
+        return hipErrorInvalidValue;
+    if (a.nStrips != 1 && flavour != kPairSwStrips && flavour != kPairGlobalStrips) return hipErrorInvalidValue;
     switch (flavour) {
         case kPairGlobalBiased:
             // (end locations are a run-time option of this kernel: a.endI != nullptr)
@@ -70,6 +71,16 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
             }
             if (rowsPerStrip < 48) return launchInterseqPairSwStripsA(a, rowsPerStrip, computeUnits, stream);
             return launchInterseqPairSwStripsB(a, rowsPerStrip, computeUnits, stream);
+        case kPairGlobalStrips:
+            if (rowsPerStrip < 32 || rowsPerStrip > (locate ? kPairStripsMaxRowsLoc : kPairStripsMaxRows) || (rowsPerStrip & 1))
+                return hipErrorInvalidValue;
+            if (locate) {
+                // (end locations leave as keys: decode_global_keys_kernel)
+                if (rowsPerStrip < 48) return launchInterseqPairGlobalStripsLocA(a, rowsPerStrip, computeUnits, stream);
+                return launchInterseqPairGlobalStripsLocB(a, rowsPerStrip, computeUnits, stream);
+            }
+            if (rowsPerStrip < 48) return launchInterseqPairGlobalStripsA(a, rowsPerStrip, computeUnits, stream);
+            return launchInterseqPairGlobalStripsB(a, rowsPerStrip, computeUnits, stream);
         case kPairSwHalf: return launchInterseqPairSwHalf(a, rowsPerStrip, computeUnits, stream);
         case kPairSwInt16: return launchInterseqPairSwInt16(a, rowsPerStrip, computeUnits, stream);
     }

@@ -1,0 +1,11 @@
+// One arithmetic flavour of the inter-sequence kernel (see interseq_impl.h): NW / HW / OV of several
+// strips on biased integer halves with the pair-indexed LDS profile; strips of 48..52 rows.
+#include "interseq_impl.h"
+
+namespace miopal {
+
+hipError_t launchInterseqPairGlobalStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream) {
+    return launchPairGlobalStrips<48, false>(a, rows, computeUnits, stream);
+}
+
+}  // namespace miopal

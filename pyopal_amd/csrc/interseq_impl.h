@@ -1408,6 +1408,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
     int* ctl = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);   // 16 bytes behind the table
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int tableStrip = -1;
+    const int spinCap = a.stripSpinCap > 0 ? a.stripSpinCap : kStripSpinCap;
 
     for (;;) {
         if (threadIdx.x == 0) {
@@ -1475,7 +1476,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         // chunks the strip above must be ahead: the rows of columns up to j + (rows ahead) are fetched
         constexpr int kLag = 1 + (MIOPAL_STRIP_ROWS_AHEAD + 3) / 4;
         int avail = fromAbove ? 0 : nChunks;   // chunks of the strip above known to be published
-        bool dead = false;
+        // (test hook, host.hip miopalTestInjectFault: this unit behaves like one that died - no sweep, no
+        // progress published, its lanes flagged - so that the strip below runs into its time-out)
+        const bool injected = u + 1 == a.faultUnit1;
+        bool dead = injected;
         auto waitFor = [&](int need) {
             // (wave-uniform: every lane reads the same counter)
             int spins = 0;
@@ -1483,14 +1487,14 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 avail = stripPoll(progIn);
                 if (avail >= need) break;
                 __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
-                if (++spins > kStripSpinCap) avail = kStripPoison;
+                if (++spins > spinCap) avail = kStripPoison;
                 // (the unit above may never be taken once the launch has given up)
                 if (a.stripAbort && __hip_atomic_load(a.stripAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.stripAbortAt)
                     avail = kStripPoison;
             }
             if (avail >= kStripPoison) dead = true;
         };
-        waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
+        if (!dead) waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
 
         uint32_t best = 0u;                 // true values (LOC: keys), integer order
         int colA = -1, colB = -1;           // LOC: column of the first maximum of each half in this strip
@@ -1635,7 +1639,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         const size_t base = (size_t)g * kGroupTargets;
         if (dead) {
             // the strip above never got here: leave the answer to the next rung, tell the strip below
-            if (toBelow && lane == 0) __hip_atomic_store(progOut, kStripPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (toBelow && lane == 0 && !injected) __hip_atomic_store(progOut, kStripPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (a.overflow) a.overflow[base + lane] = a.overflow[base + kLanes + lane] = 1;
             continue;
         }
@@ -1996,6 +2000,403 @@ static hipError_t launchPairGlobal(const InterseqArgs& a, int rowsPerStrip, int 
         case 10: return launchPairGlobalR<kLo + 10>(a, computeUnits, stream);
         case 12: return launchPairGlobalR<kLo + 12>(a, computeUnits, stream);
         case 14: return launchPairGlobalR<kLo + 14>(a, computeUnits, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// H[row] for a wave-uniform, run-time `row` in [LO, HI]: a binary tree of scalar branches (the opaque
+// move in the leaves keeps the compiler from turning the tree into HI - LO selects on hoisted predicates)
+template <int LO, int HI, int N>
+static __device__ __forceinline__ uint32_t pickRow(const uint32_t (&H)[N], int row) {
+    if constexpr (LO >= HI) {
+        uint32_t v = H[LO];
+        asm volatile("" : "+v"(v));
+        return v;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (row <= MID) return pickRow<LO, MID>(H, row);
+        return pickRow<MID + 1, HI>(H, row);
+    }
+}
+
+// ---- NW / HW / OV of SEVERAL strips on the pair table (round 3) ---------------------
+// The one-strip kernel's cell above (3 integer adds + 3 max per cell pair, no v_perm) in the unit scheme
+// of interseq_pair_strips_kernel: a workgroup takes (batch of up to 12 groups, strip) units from a
+// counter, strip-major, rebuilds its pair table when the strip changes, and the last row of a strip
+// reaches the strip below through HBM as relaxed agent-scope atomics behind a progress counter
+// (stripPublish / stripPoll, common.h). What the modes without a floor need on top:
+//  * borders: the left border H[i][-1] of the strip's own rows as running sums, the top border only in
+//    strip 0 (the other strips start from the row above), both as wave-uniform patterns;
+//  * the scale: a half holds zero + x + sigma(j). With a free top border (HW, OV) x is bounded by the
+//    QUERY (not the strip) and sigma is rebased at the same chunks in every strip, so a pattern means
+//    the same on both sides of a boundary; with a penalised one (NW) x + j ext is bounded and sigma
+//    just grows. The host checks the static range for the whole query (host.hip, globalStrips);
+//  * answers: only the last strip holds the last query row (NW: its value at each lane's own last
+//    column; HW / OV: maximum over the columns), and OV also takes the maximum over the rows of each
+//    target's last column, strip by strip.
+//    Scores only (LOC = false): the last strip stores the last-row answer (NW, HW) or every strip folds
+//    its candidates into the view scores with atomicMax (OV; the host fills them with INT32_MIN).
+//    With end locations (LOC = true) every candidate becomes a 64-bit key
+//      (score + 2^31) << 32 | last-row candidate << 31 | 0x7FFFFFFF - (column | row)
+//    merged with atomicMax: highest score; at equal scores the last row before the last column (the scan
+//    order of oracle/opal_oracle.c), then the smallest column / row. decode_global_keys_kernel
+//    (pack.hip) turns the keys into view-order scores and end locations. The row and column
+//    bookkeeping costs registers: strips of at most 48 rows (52 without);
+//  * nothing leaves its range, so nothing is flagged - except the lanes of a unit whose strip above
+//    never arrived (time-out escape, as in the Smith-Waterman kernel): they are flagged for the int32
+//    kernel and the strip below is told (poison).
+template <int R, bool LOC>
+__global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_strips_kernel(InterseqArgs a) {
+    constexpr int SLOTS = PairLayout<R>::kRowSlots;
+    constexpr int NB4 = (R + 3) / 4;
+    extern __shared__ uint4 pairs[];
+
+    const int lane = threadIdx.x & 63;
+    const int nSym = a.nSymbols;
+    const int ext = a.gapExt, open = a.gapOpen, Q = a.qLen;
+    const int zero = a.biasedZero;
+    const bool topGap = a.topGap, leftGap = a.leftGap;
+    const int region = a.region;
+    const uint32_t ext2 = both(ext), openMinusExt2 = both(open - ext);
+    const int nStrips = a.nStrips;
+    const int perBatch = a.batchGroups;
+    const int nBatches = (a.nGroups + perBatch - 1) / perBatch;
+    int* ctl = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);   // 16 bytes behind the table
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int tableStrip = -1;
+    const int spinCap = a.stripSpinCap > 0 ? a.stripSpinCap : kStripSpinCap;
+    const int rl = Q - 1 - (nStrips - 1) * R;   // row of the last query residue inside the last strip
+
+    for (;;) {
+        if (threadIdx.x == 0) ctl[0] = atomicAdd(a.unitCounter, 1);
+        __syncthreads();   // (and: every wavefront has left the table of the unit before)
+        const int u = __builtin_amdgcn_readfirstlane(ctl[0]);
+        if (u >= nBatches * nStrips) break;
+        const int s = u / nBatches, b = u - s * nBatches;   // strip-major (see interseq_pair_strips_kernel)
+        if (s != tableStrip) {
+            // (s + ext) of both targets as one integer; padding symbol / rows add nothing
+            const int16_t* gp = a.profile + s * R;
+            uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
+            const int total = nSym * nSym * R;
+            for (int idx = threadIdx.x; idx < total; idx += kPairWaves * kLanes) {
+                const int row = idx / R, r = idx - row * R;
+                const int tA = row / nSym, tB = row - tA * nSym;
+                const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
+                const int sA = vA == kBiasedPadScore ? 0 : vA + ext;
+                const int sB = vB == kBiasedPadScore ? 0 : vB + ext;
+                pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
+            }
+            tableStrip = s;
+        }
+        __syncthreads();   // table ready; ctl[0] read by everybody
+        const int gIdx = b * perBatch + wave;
+        if (wave >= perBatch || gIdx >= a.nGroups) continue;
+        const int g = gIdx + a.groupBase;
+        const uint2* pack = a.pack + a.groupOff[g];
+        const int nChunks = gIdx < a.capGroups ? min(a.groupChunks[g], a.capChunks) : a.groupChunks[g];
+        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+        const bool fromAbove = s > 0, toBelow = s + 1 < nStrips;
+        unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + a.boundaryOff[g]);
+        unsigned long long* bout = reinterpret_cast<unsigned long long*>(a.boundary[s & 1] + a.boundaryOff[g]);
+        auto loadRow = [&](int col) -> uint2 {
+            const unsigned long long v = __hip_atomic_load(bin + (uint32_t)(col * kLanes + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+        };
+        int* progOut = a.unitFlags + (size_t)gIdx * nStrips + s;
+        const int* progIn = progOut - 1;
+        const int lastCol = nChunks * 4 - 1;
+        constexpr int kLag = 1 + (MIOPAL_STRIP_ROWS_AHEAD + 3) / 4;
+        int avail = fromAbove ? 0 : nChunks;   // chunks of the strip above known to be published
+        // (test hook, host.hip miopalTestInjectFault: this unit behaves like one that died - no sweep, no
+        // progress published, its lanes flagged - so that the strip below runs into its time-out)
+        const bool injected = u + 1 == a.faultUnit1;
+        bool dead = injected;
+        auto waitFor = [&](int need) {
+            int spins = 0;
+            while (avail < need) {
+                avail = stripPoll(progIn);
+                if (avail >= need) break;
+                __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
+                if (++spins > spinCap) avail = kStripPoison;
+            }
+            if (avail >= kStripPoison) dead = true;
+        };
+        if (!dead) waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
+
+        const size_t base = (size_t)g * kGroupTargets;
+        const int lenA = a.lens[base + lane], lenB = a.lens[base + kLanes + lane];
+        // candidates (true values) of this unit: last query row (last strip), last column (OV, any strip);
+        // their columns / rows only with LOC
+        int runA = INT32_MIN, runB = INT32_MIN, colA = -1, colB = -1;
+        int cbA = INT32_MIN, cbB = INT32_MIN, crowA = -1, crowB = -1;
+
+        // the sweep, compiled for the three kinds of strip (first / inner / last)
+        auto sweep = [&](auto fromAboveC, auto toBelowC) {
+            constexpr bool kFromAbove = decltype(fromAboveC)::value, kToBelow = decltype(toBelowC)::value;
+            int sigma = zero - ext;             // zero + sigma(j) of the last column done (column -1 here)
+            int shift = -ext;                   // part of sigma accumulated since the last rebase
+            uint32_t H[R], E[R];
+            {
+                // H[i][-1], i = s R + r: one gap of i + 1 residues or i + 1 one-residue gaps (borderGap), as
+                // running sums in VECTOR registers (wave-uniform values: left to itself the compiler keeps
+                // all 2 R of them in scalar registers first, and spills hundreds)
+                const int i0 = s * R;
+                int one = open + i0 * ext, many = (i0 + 1) * open;
+                asm volatile("" : "+v"(one), "+v"(many));
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int left = leftGap ? -min(one, many) : 0;
+                    H[r] = both(zero - ext + left);                   // on column -1's scale
+                    E[r] = both(zero + left - open);                  // E[i][0] on column 0's scale
+                    one += ext;
+                    many += open;
+                }
+            }
+            constexpr int kRowsAhead = MIOPAL_STRIP_ROWS_AHEAD;
+            uint2 bq[kRowsAhead + 1];
+#pragma unroll
+            for (int x = 0; x <= kRowsAhead; ++x) bq[x] = make_uint2(0u, 0u);
+            // H of the row above at column j - 1, on that column's scale: the left border of row s R - 1
+            uint32_t hbPrev = 0u;
+            if constexpr (kFromAbove) {
+                hbPrev = both(zero - ext + (leftGap ? borderGap(s * R - 1, open, ext) : 0));
+#pragma unroll
+                for (int x = 0; x < kRowsAhead; ++x) bq[x] = loadRow(min(x, lastCol));
+            }
+            uint2 cur = pack[lane];
+            auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
+                const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
+                return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
+                                                      __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
+            };
+            constexpr int kWant = R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
+            constexpr int kAhead = NB4 > kWant ? kWant : 1;
+            const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
+            uint4 vn[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+            // top border of the matrix (strip 0), as running values: H[-1][j - 1] and H[-1][j]
+            int topPrev = 0, topHere = topGap ? borderGap(0, open, ext) : 0;
+            for (int c = 0; c < nChunks && !dead; ++c) {
+                uint2 nxt = {0, 0};
+                if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+                if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
+                uint32_t ra = cur.x, rb = cur.y;
+#pragma unroll 1
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int j = c * 4 + cc;
+                    const uint4* prow = prowNext;
+                    uint4 v[NB4];
+#pragma unroll
+                    for (int k = 0; k < kAhead; ++k) v[k] = vn[k];
+                    if constexpr (kFromAbove) bq[kRowsAhead] = loadRow(min(j + kRowsAhead, lastCol));
+                    ra = cc < 3 ? ra >> 8 : nxt.x;
+                    rb = cc < 3 ? rb >> 8 : nxt.y;
+                    prowNext = rowOf(ra & 0xffu, rb & 0xffu);
+                    auto score = [&](int r) -> uint32_t {
+                        const uint4 x = v[r >> 2];
+                        const int k = r & 3;
+                        return k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                    };
+                    uint32_t dsum, f;
+                    if constexpr (kFromAbove) {
+                        dsum = hbPrev + score(0);       // the row above at column j - 1, one column to the right
+                        sigma += ext;
+                        f = bq[0].y;                    // F entering the strip's first row, on this column's scale
+                    } else {
+                        // row above the matrix: H[-1][j-1] on the previous column's scale, H[-1][j] on this one's
+                        dsum = both(sigma + topPrev) + score(0);
+                        sigma += ext;
+                        f = both(sigma + topHere - open);
+                        asm volatile("" : "+v"(f));
+                        topPrev = topHere;
+                        if (topGap) topHere = borderGap(j + 1, open, ext);
+                    }
+#pragma unroll
+                    for (int r4 = 0; r4 < NB4; ++r4) {
+                        if (r4 + kAhead < NB4) v[r4 + kAhead] = prow[r4 + kAhead];
+                        if (r4 == (NB4 > 3 ? NB4 - 3 : 0)) {
+#pragma unroll
+                            for (int k = 0; k < kAhead; ++k) vn[k] = prowNext[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int r = r4 * 4 + k;
+                            if (r >= R) continue;
+                            uint32_t dnext = 0;
+                            if (r + 1 < R) dnext = H[r] + score(r + 1);
+                            const uint32_t h = pk_max3_f16(dsum, E[r], f);
+                            const uint32_t hmo = h - openMinusExt2;
+                            E[r] = pk_max3_f16(E[r], hmo, hmo);
+                            asm volatile("" : "+v"(E[r]));
+                            // (after the last row: what the strip below starts from)
+                            if (kToBelow || r + 1 < R) f = pk_max3_f16(f, hmo, hmo) - ext2;
+                            H[r] = h;
+                            dsum = dnext;
+                        }
+                        asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
+#pragma unroll
+                        for (int k = 1; k <= 4; ++k)
+                            if (r4 * 4 + 3 + k < R) asm volatile("" : "+v"(H[r4 * 4 + 3 + k]));
+                    }
+                    if constexpr (kToBelow)
+                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane), ((unsigned long long)f << 32) | H[R - 1],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if constexpr (kFromAbove) {
+                        hbPrev = bq[0].x;
+#pragma unroll
+                        for (int x = 0; x < kRowsAhead; ++x) bq[x] = bq[x + 1];
+                    }
+                    // ---- answers
+                    if constexpr (!kToBelow) {
+                        // the last query row: row rl of this strip, the same for the whole launch - usually
+                        // the strip's last (the host prefers strip heights that divide the query). Otherwise a
+                        // tree of wave-uniform BRANCHES finds it (selects would be R hoisted scalar predicates).
+                        uint32_t hq = H[R - 1];
+                        if (rl != R - 1) hq = pickRow<0, R - 2>(H, rl);
+                        const int qA = (int)(hq & 0xffffu) - sigma, qB = (int)(hq >> 16) - sigma;
+                        if (region == kLastCell) {
+                            if (j == lenA - 1) { runA = qA; if (LOC) colA = j; }
+                            if (j == lenB - 1) { runB = qB; if (LOC) colB = j; }
+                        } else {
+                            // HW scans columns < len, OV columns < len - 1 (its last column is scanned row by row)
+                            const int cut = region == kLastRowCol ? 1 : 0;
+                            if (j < lenA - cut && qA > runA) { runA = qA; if (LOC) colA = j; }
+                            if (j < lenB - cut && qB > runB) { runB = qB; if (LOC) colB = j; }
+                        }
+                    }
+                    if (region == kLastRowCol) {
+                        const bool lastA = j == lenA - 1, lastB = j == lenB - 1;
+                        if (__builtin_amdgcn_ballot_w64(lastA || lastB) != 0) {
+                            // some lane is on its target's last column: maximum over this strip's query rows. The
+                            // patterns of one column share a scale, so the packed maximum is a chain of max3 on
+                            // both halves at once. (Rows beyond the query exist in the last strip only; their
+                            // bound is made opaque HERE so that the row predicates are not hoisted out of the
+                            // column loop into scalar register pairs.)
+                            int rows = kToBelow ? R : rl + 1;
+                            if (!kToBelow) asm volatile("" : "+v"(rows));
+                            auto rowValue = [&](int r) -> uint32_t {
+                                if (!kToBelow && r > 0) return r < rows ? H[r] : H[0];
+                                return H[r];
+                            };
+                            uint32_t m2 = rowValue(0);
+#pragma unroll
+                            for (int r = 1; r + 1 < R; r += 2) m2 = pk_max3_f16(m2, rowValue(r), rowValue(r + 1));
+                            if ((R & 1) == 0) m2 = pk_max3_f16(m2, rowValue(R - 1), rowValue(R - 1));
+                            const int mA = (int)(m2 & 0xffffu), mB = (int)(m2 >> 16);
+                            if (lastA) cbA = mA - sigma;
+                            if (lastB) cbB = mB - sigma;
+                            if constexpr (LOC) {
+                                // first row that holds the maximum of its half
+                                int ia = 0, ib = 0;
+#pragma unroll
+                                for (int r = R - 1; r >= 0; --r) {
+                                    const uint32_t d = rowValue(r) ^ m2;
+                                    if ((d & 0xffffu) == 0) ia = r;
+                                    if ((d >> 16) == 0) ib = r;
+                                    asm volatile("" : "+v"(ia), "+v"(ib));
+                                }
+                                if (lastA) crowA = s * R + ia;
+                                if (lastB) crowB = s * R + ib;
+                            }
+                        }
+                    }
+                }
+                cur = nxt;
+                shift += 4 * ext;
+                if (!topGap && shift + 4 * ext > kBiasedMaxShift) {
+                    // rebase (every strip does it after the same chunks: the rows the strip above wrote from
+                    // the next chunk on are already on the new scale, the one kept in hbPrev is not)
+                    const uint32_t d = both(shift);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        H[r] -= d;
+                        E[r] -= d;
+                    }
+                    if constexpr (kFromAbove) hbPrev -= d;
+                    sigma -= shift;
+                    shift = 0;
+                }
+                if (kToBelow && (((c + 1) & 3) == 0 || c + 1 == nChunks)) stripPublish(progOut, c + 1, lane);
+            }
+        };
+        if (!dead) {
+            if (!fromAbove && toBelow) sweep(std::false_type{}, std::true_type{});
+            else if (fromAbove && toBelow) sweep(std::true_type{}, std::true_type{});
+            else if (fromAbove) sweep(std::true_type{}, std::false_type{});
+            // (a single strip is the one-strip kernel's business: launchPairGlobalStrips refuses it)
+        }
+        if (dead) {
+            // the strip above never got here: leave the answers to the int32 kernel, tell the strip below
+            if (toBelow && lane == 0 && !injected) __hip_atomic_store(progOut, kStripPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.overflow) a.overflow[base + lane] = a.overflow[base + kLanes + lane] = 1;
+            continue;
+        }
+        if constexpr (LOC) {
+            auto key = [](int score, bool onLastRow, int index) -> unsigned long long {
+                return ((unsigned long long)((uint32_t)score ^ 0x80000000u) << 32) | (onLastRow ? 0x80000000ull : 0ull) |
+                       (unsigned long long)(0x7FFFFFFFu - (uint32_t)index);
+            };
+            if (!toBelow) {
+                if (colA >= 0) atomicMax(a.stripKeys + base + lane, key(runA, true, colA));
+                if (colB >= 0) atomicMax(a.stripKeys + base + kLanes + lane, key(runB, true, colB));
+            }
+            if (region == kLastRowCol) {
+                if (crowA >= 0) atomicMax(a.stripKeys + base + lane, key(cbA, false, crowA));
+                if (crowB >= 0) atomicMax(a.stripKeys + base + kLanes + lane, key(cbB, false, crowB));
+            }
+        } else if (region == kLastRowCol) {
+            // OV: every strip's last-column maximum and the last strip's last-row maximum (INT32_MIN: none)
+            atomicMax(a.score + base + lane, max(runA, cbA));
+            atomicMax(a.score + base + kLanes + lane, max(runB, cbB));
+        } else if (!toBelow) {
+            a.score[base + lane] = runA;
+            a.score[base + kLanes + lane] = runB;
+        }
+    }
+}
+
+template <int R, bool LOC>
+static hipError_t launchPairGlobalStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + the unit in flight
+    static uint64_t configured = 0;  // one bit per device
+    if (firstUseOnThisDevice(&configured)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_global_strips_kernel<R, LOC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
+    }
+    const int nBatches = (a.nGroups + a.batchGroups - 1) / a.batchGroups;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(computeUnits, (int64_t)nBatches * a.nStrips));
+    hipLaunchKernelGGL((interseq_pair_global_strips_kernel<R, LOC>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int kLo, int kStep, bool LOC>
+static hipError_t launchPairGlobalStripsCase(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
+    if constexpr (kLo + kStep <= (LOC ? kStripsMaxRowsLoc : kStripsMaxRows))
+        return launchPairGlobalStripsR<kLo + kStep, LOC>(a, computeUnits, stream);
+    else return hipErrorInvalidValue;
+}
+template <int kLo, bool LOC>
+static hipError_t launchPairGlobalStrips(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
+    if (a.nStrips < 2 || !a.unitCounter || !a.unitFlags || !a.boundary[0] || !a.boundary[1] || a.batchGroups < 1 ||
+        a.batchGroups > kPairWaves || (LOC && !a.stripKeys) || a.region == kAllCells)
+        return hipErrorInvalidValue;
+    switch (rowsPerStrip - kLo) {
+        case 0: return launchPairGlobalStripsCase<kLo, 0, LOC>(a, computeUnits, stream);
+        case 2: return launchPairGlobalStripsCase<kLo, 2, LOC>(a, computeUnits, stream);
+        case 4: return launchPairGlobalStripsCase<kLo, 4, LOC>(a, computeUnits, stream);
+        case 6: return launchPairGlobalStripsCase<kLo, 6, LOC>(a, computeUnits, stream);
+        case 8: return launchPairGlobalStripsCase<kLo, 8, LOC>(a, computeUnits, stream);
+        case 10: return launchPairGlobalStripsCase<kLo, 10, LOC>(a, computeUnits, stream);
+        case 12: return launchPairGlobalStripsCase<kLo, 12, LOC>(a, computeUnits, stream);
+        case 14: return launchPairGlobalStripsCase<kLo, 14, LOC>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -277,6 +277,13 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
         }
         return;
     }
+    if (unit + 1 == a.faultUnit1) {
+        // (test hook, host.hip miopalTestInjectFault: this unit publishes nothing, the strip below it
+        // runs into its time-out)
+        if (lane == 0) *partial = make_int4(0, -1, -1, 0);
+        return;
+    }
+    const int waitCap = a.stripWaitCap > 0 ? a.stripWaitCap : kStripWaitCap;
     if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
     const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
     const int hFloor = floor0 ? 0 : INT32_MIN;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel
                     avail = stripPoll(progIn);
                     if (avail >= need) break;
                     __builtin_amdgcn_s_sleep(4);
-                    if (++spins > kStripWaitCap) {
+                    if (++spins > waitCap) {
                         dead = true;
                         break;
                     }

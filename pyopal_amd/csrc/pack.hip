@@ -144,6 +144,22 @@ __global__ void decode_strip_keys_kernel(const unsigned long long* keys, int n, 
     endJ[k] = key != 0 ? (int)(0xFFFFFull - ((key >> 20) & 0xFFFFFull)) : -1;
 }
 
+// keys of the multi-strip NW / HW / OV pair-table kernel (interseq_impl.h):
+// (score + 2^31) << 32 | last-row candidate << 31 | 0x7FFFFFFF - (column | row); an untouched key belongs
+// to an absent or empty target, or to lanes the int32 kernel recomputes (endI / endJ may be null)
+__global__ void decode_global_keys_kernel(const unsigned long long* keys, const int32_t* lens, int n, int queryLength,
+                                          int32_t* score, int32_t* endI, int32_t* endJ) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long key = keys[k];
+    const uint32_t low = (uint32_t)key;
+    const int index = (int)(0x7FFFFFFFu - (low & 0x7FFFFFFFu));
+    const bool onLastRow = (low >> 31) != 0;
+    score[k] = key != 0 ? (int)((uint32_t)(key >> 32) ^ 0x80000000u) : INT32_MIN;
+    if (endI) endI[k] = key == 0 ? -1 : onLastRow ? queryLength - 1 : index;
+    if (endJ) endJ[k] = key == 0 ? -1 : onLastRow ? index : lens[k] - 1;
+}
+
 __global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = value;
@@ -172,6 +188,14 @@ hipError_t launchDecodeStripKeys(const unsigned long long* keys, int n, int32_t*
                                  hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(decode_strip_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, n, score, endI, endJ);
+    return hipGetLastError();
+}
+
+hipError_t launchDecodeGlobalKeys(const unsigned long long* keys, const int32_t* lens, int n, int queryLength,
+                                  int32_t* score, int32_t* endI, int32_t* endJ, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_global_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, lens, n, queryLength,
+                       score, endI, endJ);
     return hipGetLastError();
 }
 

@@ -88,3 +88,12 @@ def test_reference_entry_point_without_device(capi):
         assert call(1) == capi.OPAL_ERR_NO_SIMD_SUPPORT
         assert res.scoreSet == 0                          # no result was made up
         lib.miopalReleaseCaches()
+
+
+@pytest.mark.timeout(60)
+def test_view_cache_survives_a_throwing_builder(capi):
+    # host.hip getViewWith: a builder that throws (std::bad_alloc from a million-entry vector, or
+    # whatever parallelSlices rethrows) must not leave its placeholder behind - every later search of
+    # the slice would wait on it forever. Needs no device: the builders are injected (miopalSelfTest).
+    assert capi.lib().miopalSelfTest(1) == 0
+    assert capi.lib().miopalSelfTest(99) != 0    # unknown test number
