@@ -1940,6 +1940,8 @@ struct Search {
                 // few (group, strip) units: fewer groups per workgroup, so that every CU gets a unit and a
                 // wavefront shares its SIMD with fewer others
                 ia.batchGroups = (int)std::max<int64_t>(1, std::min<int64_t>(12, (int64_t)ia.nGroups * nStrips / std::max(1, pairUnits)));
+                if (const char* bg = getenv("MIOPAL_BATCH_GROUPS"))   // experiments
+                    ia.batchGroups = std::max(1, std::min(12, atoi(bg)));
                 hipError_t pe = hipSuccess;
                 // (random pairs only get there in the linear regime of the scoring system, and then score
                 // about half a unit per aligned residue: nothing to probe for under ~500 residues)

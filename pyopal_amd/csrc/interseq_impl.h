@@ -1384,6 +1384,50 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 #ifndef MIOPAL_STRIP_SLACK
 #define MIOPAL_STRIP_SLACK 0
 #endif
+// Pacing of the wavefronts that share a SIMD (round 3). The twelve wavefronts of a unit sweep groups of
+// (nearly) equal length and meet at the unit's barrier, but a SIMD serves its OLDEST ready wavefront
+// first: of three with equal work the first is done after little more than half the unit's time, the
+// last sweeps the rest of its group alone on a SIMD it cannot fill, and meanwhile the others wait at the
+// barrier (PMC of the round-2 kernel on BASELINE configs[3]: wavefronts parked 47 % of their life,
+// 15 % in the one-strip kernel whose wavefronts fetch new groups on their own). Each wavefront
+// therefore publishes the chunk it is on in LDS, per hardware SIMD, and the one furthest behind runs at
+// a higher priority: the three advance together and reach the barrier together.
+#ifndef MIOPAL_STRIP_PACE
+#define MIOPAL_STRIP_PACE 1
+#endif
+constexpr int kPaceInts = 20;   // 4 SIMDs x 4 slots of progress + 4 slot counters
+struct SimdPace {
+    int* mine = nullptr;        // this wavefront's progress word
+    const int4* simdRow = nullptr;
+    // (once per kernel; `lds` = kPaceInts ints, every thread of the workgroup calls this)
+    __device__ __forceinline__ void init(int* lds, int lane) {
+        if (threadIdx.x < kPaceInts) lds[threadIdx.x] = threadIdx.x < 16 ? INT32_MAX : 0;
+        __syncthreads();
+        // HW_REG_HW_ID (4), SIMD_ID = bits 5:4
+        const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&lds[16 + simd], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot) & 3;
+        mine = lds + simd * 4 + slot;
+        simdRow = reinterpret_cast<const int4*>(lds + simd * 4);
+    }
+    __device__ __forceinline__ void begin(int lane) const {
+        if (MIOPAL_STRIP_PACE && lane == 0) *mine = 0;
+    }
+    __device__ __forceinline__ void end(int lane) const {
+        if (MIOPAL_STRIP_PACE && lane == 0) *mine = INT32_MAX;   // (at the barrier: nobody waits for this one)
+    }
+    // at the top of chunk c; `fixed`: the wavefront keeps the priority it has (a long group)
+    __device__ __forceinline__ void step(int c, int lane, bool fixed) const {
+        if (!MIOPAL_STRIP_PACE || fixed) return;
+        if (lane == 0) *mine = c;
+        const int4 p = *simdRow;
+        const int behind = __builtin_amdgcn_readfirstlane(min(min(p.x, p.y), min(p.z, p.w)));
+        if (c <= behind) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
 constexpr int kStripPoison = 1 << 30;
 constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
 
@@ -1409,6 +1453,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int tableStrip = -1;
     const int spinCap = a.stripSpinCap > 0 ? a.stripSpinCap : kStripSpinCap;
+    SimdPace pace;
+    pace.init(ctl + 4, lane);
 
     for (;;) {
         if (threadIdx.x == 0) {
@@ -1454,7 +1500,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         // (a leading group whose longest targets were handed to the int32 kernel stops at the longest that stays)
         const int nChunks = gIdx < a.capGroups ? min(a.groupChunks[g], a.capChunks) : a.groupChunks[g];
         // (a long group is the launch's critical path: it wins the SIMD's issue arbitration)
-        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        const bool longGroup = nChunks > a.priorityChunks;
+        if (longGroup) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
         const bool fromAbove = s > 0, toBelow = s + 1 < nStrips;
         // boundary rows: [column][lane] (H, F) of the strip's last row
@@ -1536,6 +1583,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             for (int c = 0; c < nChunks && !dead; ++c) {
                 uint2 nxt = {0, 0};
                 if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+                pace.step(c, lane, longGroup);
                 if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
                 uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
@@ -1632,9 +1680,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             }
         };
         if (!dead) {
+            pace.begin(lane);
             if (!fromAbove) sweep(std::false_type{}, std::true_type{});
             else if (toBelow) sweep(std::true_type{}, std::true_type{});
             else sweep(std::true_type{}, std::false_type{});
+            pace.end(lane);
         }
         const size_t base = (size_t)g * kGroupTargets;
         if (dead) {
@@ -1674,7 +1724,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
 
 template <int R, bool LOC>
 static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + the unit in flight
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16 + kPaceInts * sizeof(int);  // table + the unit in flight + pacing
     static uint64_t configured = 0;  // one bit per device
     if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R, LOC>),
@@ -2066,6 +2116,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
     int tableStrip = -1;
     const int spinCap = a.stripSpinCap > 0 ? a.stripSpinCap : kStripSpinCap;
     const int rl = Q - 1 - (nStrips - 1) * R;   // row of the last query residue inside the last strip
+    SimdPace pace;
+    pace.init(ctl + 4, lane);
 
     for (;;) {
         if (threadIdx.x == 0) ctl[0] = atomicAdd(a.unitCounter, 1);
@@ -2094,7 +2146,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
         const int g = gIdx + a.groupBase;
         const uint2* pack = a.pack + a.groupOff[g];
         const int nChunks = gIdx < a.capGroups ? min(a.groupChunks[g], a.capChunks) : a.groupChunks[g];
-        if (nChunks > a.priorityChunks) __builtin_amdgcn_s_setprio(3);
+        const bool longGroup = nChunks > a.priorityChunks;
+        if (longGroup) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
         const bool fromAbove = s > 0, toBelow = s + 1 < nStrips;
         unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + a.boundaryOff[g]);
@@ -2181,6 +2234,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
             for (int c = 0; c < nChunks && !dead; ++c) {
                 uint2 nxt = {0, 0};
                 if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+                pace.step(c, lane, longGroup);
                 if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
                 uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
@@ -2322,10 +2376,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
             }
         };
         if (!dead) {
+            pace.begin(lane);
             if (!fromAbove && toBelow) sweep(std::false_type{}, std::true_type{});
             else if (fromAbove && toBelow) sweep(std::true_type{}, std::true_type{});
             else if (fromAbove) sweep(std::true_type{}, std::false_type{});
             // (a single strip is the one-strip kernel's business: launchPairGlobalStrips refuses it)
+            pace.end(lane);
         }
         if (dead) {
             // the strip above never got here: leave the answers to the int32 kernel, tell the strip below
@@ -2359,7 +2415,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
 
 template <int R, bool LOC>
 static hipError_t launchPairGlobalStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + the unit in flight
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16 + kPaceInts * sizeof(int);  // table + the unit in flight + pacing
     static uint64_t configured = 0;  // one bit per device
     if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_global_strips_kernel<R, LOC>),
