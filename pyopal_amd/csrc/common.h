@@ -105,6 +105,7 @@ struct IntraseqArgs {
     int* stripProgress;       // zeroed, [nJobs x nStrips]: columns of the strip's last row published
     int4* stripPartial;       // [nJobs x nStrips]: (score, row, column) of the strip
     int* error;               // incremented by a unit that gave up waiting (never seen)
+    int fatBlocks;            // workgroups of 16 wavefronts (beside a persistent packed launch) instead of 4
     int stripWaitCap;         // polls before a unit gives up on the strip above; 0 = the default
     int faultUnit1;           // test hook: unit (this - 1) publishes nothing; 0 = none
 };

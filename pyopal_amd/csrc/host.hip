@@ -1155,6 +1155,7 @@ struct Search {
     int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
     int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
+    bool besidePersistent = false;    // the side jobs of this pass run beside a strips kernel (persistent, one workgroup per CU)
     // a score pass that starts over (refused launch, declined probe) has already put its side jobs on
     // the side stream: they are not enqueued twice, and the join still waits for them
     // test hook (miopalTestInjectFault): kind 1 = a unit of the pair-table strips kernels, 2 = a unit of
@@ -1286,6 +1287,7 @@ struct Search {
             a.error = d_stripError;
             a.stripWaitCap = faultSpinCap;
             a.faultUnit1 = faultKind == 2 ? faultUnit + 1 : 0;
+            a.fatBlocks = besidePersistent && !getenv("MIOPAL_THIN_SIDE") ? 1 : 0;
             HIP_TRY(launchIntraseqStrips(a, on));
             return 0;
         }
@@ -1792,18 +1794,34 @@ struct Search {
                                    return std::binary_search(sideDone.begin(), sideDone.end(), j.out);
                                }), sideJobs.end());
             }
-            if (!sideJobs.empty() && !getenv("MIOPAL_NO_SIDE_STREAM")) {
-                RC_TRY(ws->ensureAux());
-                RC_TRY(ensurePairInputs());
-                HIP_TRY(hipEventRecord(ws->evFork, stream));
-                HIP_TRY(hipStreamWaitEvent(ws->aux, ws->evFork, 0));
+            // The side kernel is handed to its stream BEFORE the packed launch: its wavefronts are dispatched
+            // first, over the whole chip, and the persistent packed workgroups (one per CU, every register of
+            // it) start on a CU when its side wavefronts are done. (Handed over after the packed launch the
+            // side kernel only finds the CUs the launch left out: cfg4 with its tail, 8 CUs: 54 against 44 ms,
+            // MIOPAL_PACKED_FIRST.) Beside a strips kernel the side units come in workgroups of 16 wavefronts,
+            // so that they hold few CUs (launchIntraseqStrips), and the packed launch takes EVERY CU: the
+            // workgroups that start late simply take fewer units.
+            bool sidePending = false;
+            auto enqueueSide = [&]() -> int {
                 RC_TRY(runPairs(sideJobs, false, d_score, d_endI, d_endJ, nullptr, ws->aux, kAuxJobs - kJobs));
                 HIP_TRY(hipEventRecord(ws->evJoin, ws->aux));
                 for (const PairJob& j : sideJobs) sideDone.push_back(j.out);
                 std::sort(sideDone.begin(), sideDone.end());
                 sideJobs.clear();
-                forked = sideForked = true;
+                sidePending = false;
+                sideForked = true;   // (a score pass that starts over still joins what is on the side stream)
                 spt.mark("    side jobs enqueued");
+                return 0;
+            };
+            if (!sideJobs.empty() && !getenv("MIOPAL_NO_SIDE_STREAM")) {
+                RC_TRY(ws->ensureAux());
+                RC_TRY(ensurePairInputs());
+                HIP_TRY(hipEventRecord(ws->evFork, stream));
+                HIP_TRY(hipStreamWaitEvent(ws->aux, ws->evFork, 0));
+                forked = true;
+                sidePending = true;
+                besidePersistent = pairStrips;
+                if (!getenv("MIOPAL_PACKED_FIRST")) RC_TRY(enqueueSide());
             }
             void *pp, *vs, *vo, *ct;
             RC_TRY(ws->get(kProfile, prof.size() * sizeof(int16_t), &pp));
@@ -1929,11 +1947,10 @@ struct Search {
                 int pairUnits = db->computeUnits;
                 if (const char* r = getenv("MIOPAL_RESERVE_CUS"))
                     pairUnits = std::max(1, pairUnits - std::max(0, atoi(r)));
-                else if (forked)
-                    // The persistent workgroups hold their CU's registers for the whole launch: the
-                    // wavefront-per-pair kernel on the side stream only finds room as they leave, i.e. it
-                    // runs AFTER the packed kernel (log-normal lengths, NW at Q = 53, 6400 pairs on the side:
-                    // 2.07 ms; with CUs kept out of the persistent launch 1.66 ms). One CU per 256 pairs.
+                else if (forked && getenv("MIOPAL_STRIPS_RESERVE"))
+                    // (round 2 kept CUs out of the launch for the side kernel, one per 256 pairs, at least 8;
+                    // the units are taken dynamically, so a workgroup whose CU is busy with side wavefronts
+                    // at first just starts later and takes fewer)
                     pairUnits = std::max(1, pairUnits - (int)std::min<int64_t>(pairUnits / 4, std::max<int64_t>(8, (g_lastRouting[0] + 255) / 256)));
                 const PairFlavour stripsFlavour = globalStrips ? kPairGlobalStrips : kPairSwStrips;
                 g_lastRouting[1] = 2 + (int)stripsFlavour;
@@ -1976,6 +1993,7 @@ struct Search {
                     }
                 }
                 if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, stripsFlavour, pairUnits, stream, locate);
+                if (pe == hipSuccess && sidePending) RC_TRY(enqueueSide());
                 if (pe != hipSuccess) {
                     // (e.g. the runtime refuses 150 KB of dynamic LDS: start over on the general kernel)
                     (void)hipGetLastError();

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
 // locations only (no direction bytes), pairs of one common number of strips.
 constexpr int kStripWaitCap = 1 << 22;   // x s_sleep 4: about two seconds, then the unit gives up (a.error)
 
-__global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_strips_kernel(IntraseqArgs a) {
+// (launched as workgroups of 4 wavefronts, or of 16 beside a persistent packed launch: see launchIntraseqStrips)
+__global__ __launch_bounds__(1024) void intraseq_strips_kernel(IntraseqArgs a) {
     __shared__ int smat[kMaxAlphabet * kMatStride];
     const int A = a.alphabet;
     for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x)
@@ -879,8 +880,14 @@ hipError_t launchIntraseqStrips(const IntraseqArgs& a, hipStream_t stream) {
         return hipErrorInvalidValue;
     const int64_t units = (int64_t)a.nJobs * a.nStrips;
     if (units > INT32_MAX / 2) return hipErrorInvalidValue;
-    const int blocks = (int)((units + kJobsPerBlock - 1) / kJobsPerBlock);
-    hipLaunchKernelGGL(intraseq_strips_kernel, dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+    // Beside a persistent packed launch (one workgroup per CU holding every register of it) the units come
+    // as workgroups of 16 wavefronts: a packed workgroup cannot start on a CU that hosts even one of these
+    // wavefronts, and 1056 of them in workgroups of 4 sit on every CU of the chip for the length of the
+    // longest chain (cfg4 with its tail: the packed launch started 7 ms late); in workgroups of 16 they
+    // occupy a quarter of the CUs, the packed workgroups of the others start at once and take the units.
+    const int perBlock = a.fatBlocks ? 16 : kJobsPerBlock;
+    const int blocks = (int)((units + perBlock - 1) / perBlock);
+    hipLaunchKernelGGL(intraseq_strips_kernel, dim3(blocks), dim3(perBlock * kLanes), 0, stream, a);
     hipLaunchKernelGGL(merge_strip_partials_kernel, dim3((a.nJobs + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
