@@ -8,9 +8,13 @@
 One "step" = one search of the query against the device-resident database
 shard of every rank (weak scaling: each rank owns its own 1M x 300 shard; the
 only exchange is the gather of the int32 scores to rank 0 over RCCL).
-`value` is that search with the scores left in HBM (where the gather reads
-them); `value_host_results` is the same search with the scores delivered into a
-host buffer, the form the reference's boundary returns (N = 1).
+At N = 1 `value` is the search as the reference's boundary returns it: a blocking
+call (miopalSearch) that leaves the scores in a HOST array of the caller (a pinned
+one: the kernel writes database order straight into it; `value_host_results_pageable`
+is the same call with an ordinary array, through the library's pinned bounce buffer)
+and `value_device_results` the search with the scores left in HBM. At N > 1 (and
+with --force-collective) a step is the search with the scores left in HBM, where the
+gather reads them, plus that gather.
 `extras.cfg5_strong` is BASELINE.json configs[4]: ONE 10M x 400 database cut into
 residue-balanced contiguous shards over the ranks (strong scaling), one gather.
 Rank 0 prints one JSON line.
@@ -43,6 +47,10 @@ def parse():
     ap.add_argument("--no-cfg5", action="store_true", help="skip the 10M x 400 strong-scaling leg")
     ap.add_argument("--cfg5-targets", type=int, default=10_000_000)
     ap.add_argument("--cfg5-steps", type=int, default=5)
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1 rehearsal of the N > 1 path: a 1-rank nccl group (launch under torch.distributed.run "
+                         "--nproc-per-node 1), RCCL gather of device tensors, all_reduce of the elapsed time, "
+                         "MIOPAL_RESERVE_CUS")
     return ap.parse_args()
 
 
@@ -69,11 +77,15 @@ def main():
     if os.environ.get("MIOPAL_BENCH_SHARE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         # leave the collective's kernels a few CUs beside the persistent search kernel, so that
         # the gather of one step really runs during the next step's search
         os.environ.setdefault("MIOPAL_RESERVE_CUS", "8")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -97,9 +109,19 @@ def main():
     build_s = time.time() - t0
     on_device = backend == "nccl"
     from pyopal_amd.shard import OverlappedGather
-    pipe = OverlappedGather(outs, dst=0, on_device=on_device)
+    pipe = OverlappedGather(outs, dst=0, on_device=on_device, force=args.force_collective)
+    # N = 1: the caller's result array, pinned (the kernel writes into it; nothing is copied on the host)
+    host_out = None
+    if not collective:
+        host_pinned = torch.empty(N, dtype=torch.int32).pin_memory()
+        host_out = host_pinned.numpy()
+
+    def host_step():
+        db.search(query, matrix, 3, 1, "score", "sw", score_out=host_out)
 
     def step():
+        if not collective:
+            return host_step()
         b, buf = pipe.acquire()  # waits (stream-ordered for RCCL) for the gather that read it last
         db.search_device_scores(query, matrix, buf.data_ptr(), stream, 3, 1, "sw")
         # the one exchange of the path: per-shard scores to rank 0 (RCCL over xGMI). Issued
@@ -109,7 +131,7 @@ def main():
 
     def fence():
         pipe.drain()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,7 +148,7 @@ def main():
     out = outs[last]
     n_launch, kernel_ms = db.last_kernel_time()
     db.set_profiling(False)
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device=f"cuda:{local_rank}" if on_device else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -137,12 +159,17 @@ def main():
 
     # (correctness gate: in the cpu_baseline leg below - every score against the AVX2 port,
     # a sample against the scalar checker; the other legs never touch the code under oracle/)
-    got = out.cpu().numpy()
+    got = host_out.copy() if host_out is not None else out.cpu().numpy()
     checksum = int(got.astype(np.int64).sum())
+    device_form = None
+    if not collective:
+        # the same search with the scores left in HBM (what `value` was up to round 2)
+        device_form = device_results(db, query, matrix, outs[0], stream, Q, N, L)
+        assert np.array_equal(outs[0].cpu().numpy(), got)
 
     cfg5 = None
     if not args.no_cfg5:
-        cfg5 = cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
+        cfg5 = cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream, collective)
 
     if rank == 0:
         cells_per_step = float(Q) * N * L * world
@@ -154,8 +181,8 @@ def main():
         k_ms = kernel_ms / max(n_launch, 1)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         pmc = pmc_summary() if (N, L) == (1_000_000, 300) else None
-        host_form = host_results(db, query, matrix, Q, N, L) if world == 1 else None
-        plain_form = plain_entry(query, residues, offsets, matrix, Q, N, L, got) if world == 1 else None
+        host_form = host_results(db, query, matrix, Q, N, L) if not collective else None
+        plain_form = plain_entry(query, residues, offsets, matrix, Q, N, L, got) if not collective else None
         line = {
             "metric": "GCUPS (billion DP cells/s) SW score-only, 53aa query vs 1Mx300aa DB",
             "value": round(gcups, 1),
@@ -171,21 +198,27 @@ def main():
             # 25600; lanes that reach it are redone at int16 / int32)
             "dtype": "u16",
             "data": "synthetic",
-            # the same search with the 4 MB of scores delivered to a host buffer (miopalSearch: + D2H
-            # + sync), the form the reference's boundary returns; `value` leaves them in HBM
-            "value_host_results": host_form["gcups"] if host_form else None,
-            "ms_per_step_host_results": host_form["ms"] if host_form else None,
+            # N = 1: `value` is the blocking call with the scores in the caller's pinned host array; the same
+            # call with an ordinary (pageable) array goes through the library's pinned bounce buffer and
+            # one 4 MB copy on the host; with the scores left in HBM nothing crosses PCIe
+            "value_host_results_pageable": host_form["gcups"] if host_form else None,
+            "ms_per_step_host_results_pageable": host_form["ms"] if host_form else None,
+            "value_device_results": device_form["gcups"] if device_form else None,
+            "ms_per_step_device_results": device_form["ms"] if device_form else None,
+            "forced_collective": bool(args.force_collective),
             # opalSearchDatabase exactly as the reference binds it: N host pointers in, the database
             # uploaded and packed on every call, N result structs out (PCIe-inclusive, never `value`)
             "value_pcie_inclusive": plain_form["gcups"] if plain_form else None,
             "ms_per_step_pcie_inclusive": plain_form["ms"] if plain_form else None,
             "config": {
                 "workload": f"sw_score q{Q} (README.md:86) vs {N}x{L} uniform-random proteins per GPU, "
-                            "BLOSUM62, gap_open 3, gap_extend 1; value: scores left in HBM "
-                            "(value_host_results: scores on host)",
+                            "BLOSUM62, gap_open 3, gap_extend 1; value: "
+                            + ("scores left in HBM + RCCL gather to rank 0" if collective else
+                               "blocking miopalSearch, scores in the caller's pinned host array "
+                               "(value_device_results: scores left in HBM)"),
                 "targets_per_gpu": N, "target_length": L, "query_length": Q,
                 "sharding": f"{world} independent shards, RCCL gather of int32 scores to rank 0"
-                            if world > 1 else "single shard",
+                            if collective else "single shard",
             },
             "roofline": {
                 "bound": "hbm",
@@ -208,20 +241,38 @@ def main():
                         "lane, 0.02 B/cell): see DESIGN.md",
                 # secondary ceiling: VALU issue, from SQ_INSTS_VALU of this binary
                 "valu_issue": valu_ceiling(Q, k_ms, N, L, pmc),
+                # LDS counters of the same PMC passes (north_star: "LDS-hit counters reported"): the pair table
+                # is read with one ds_read_b128 per four query rows of a lane; two thirds of the LDS array's
+                # busy cycles are bank conflicts of the random pair rows
+                "lds": pmc["lds"] if pmc else None,
             },
             "db_build_s": round(build_s, 3),
             "score_checksum": checksum,
         }
         line["extras"] = {}
-        if world == 1 and not args.no_cpu_baseline:
+        if not collective and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(query, residues, offsets, matrix, Q, N, L, got)
             line["extras"] = extras(db, query, matrix, Q, N, L)
         if cfg5 is not None:
             line["extras"]["cfg5_strong"] = cfg5
         print(json.dumps(line), flush=True)
     db.close()
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+
+
+def device_results(db, query, matrix, out, stream, Q, N, L):
+    """The search with the scores left in HBM (miopalSearchDeviceScores), back to back on one stream."""
+    import torch
+    for _ in range(5):
+        db.search_device_scores(query, matrix, out.data_ptr(), stream, 3, 1, "sw")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(40):
+        db.search_device_scores(query, matrix, out.data_ptr(), stream, 3, 1, "sw")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 40
+    return {"ms": round(dt * 1e3, 4), "gcups": round(float(Q) * N * L / dt / 1e9, 1)}
 
 
 def valu_ceiling(Q, kernel_ms, N, L, pmc):
@@ -259,12 +310,13 @@ def library_sha256():
     return h.hexdigest()
 
 
-def pmc_summary():
-    """The newest committed PMC summary of the headline kernel, if it was taken on this very build
-    of libmiopal.so (tools/summarize_pmc.py stores the library's sha256 beside the counters)."""
+def pmc_summary(tag="headline"):
+    """The newest committed PMC summary of a workload (`headline`: the default bench command; others:
+    tools/collect_pmc.sh), if it was taken on this very build of libmiopal.so (tools/summarize_pmc.py
+    stores the library's sha256 beside the counters)."""
     import glob
     mine = library_sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_headline*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{tag}*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -273,13 +325,70 @@ def pmc_summary():
         if d.get("library_sha256") != mine:
             continue
         c = d.get("counters", {})
+        def mean(name):
+            return c.get(name, {}).get("mean_per_launch")
         return {
             "file": os.path.relpath(path, ROOT),
             "library_sha256": mine,
+            "kernel": d.get("kernel"),
             "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
-            "valu_instructions_per_launch": c.get("SQ_INSTS_VALU", {}).get("mean_per_launch"),
+            "valu_instructions_per_launch": mean("SQ_INSTS_VALU"),
+            # LDS: cycles the LDS arrays were busy, the extra cycles of bank conflicts among them, and the
+            # wave-cycles instructions could not issue for the LDS (quad-cycle units, per launch)
+            "lds": {"idx_active": mean("SQ_LDS_IDX_ACTIVE"), "bank_conflict": mean("SQ_LDS_BANK_CONFLICT"),
+                    "wait_inst_lds": mean("SQ_WAIT_INST_LDS"), "wave_cycles": mean("SQ_WAVE_CYCLES"),
+                    "bank_conflict_fraction": d.get("lds_bank_conflict_fraction")},
+            "wave_cycle_fractions": d.get("fractions_of_wave_cycles"),
         }
     return None
+
+
+LANE_KERNELS = {1: "interseq_kernel (general, v_perm profile)", 2: "interseq_pair_kernel<int16>", 3: "interseq_pair_kernel<half>",
+                4: "interseq_pair_biased_kernel", 5: "interseq_pair_global_kernel", 6: "interseq_pair_strips_kernel",
+                7: "interseq_pair_global_strips_kernel"}
+
+
+def leg_roofline(kernel_ms, cells, alg_bytes, routing, pmc_tag, boundary_bytes=None, kernel=None):
+    """The mandated HBM roofline of one secondary leg (the bound per config):
+    algorithmic bytes over the dominant kernel's HIP-event time, and where that kernel stands against
+    the SIMDs' issue rate when a PMC summary of this very build exists (null otherwise)."""
+    pmc = pmc_summary(pmc_tag) if pmc_tag else None
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    valu = None
+    if pmc and pmc.get("valu_instructions_per_launch") and kernel_ms > 0:
+        instr = pmc["valu_instructions_per_launch"]
+        full = 1024 * 2.4e9 / 2.0 / instr * cells / 1e9
+        valu = {"instructions_per_cell_pair": round(instr * 128.0 / cells, 3),
+                "cycles_per_instruction": round(kernel_ms * 1e-3 * 2.4e9 * 1024 / instr, 3),
+                "full_rate_peak_gcups": round(full, 1), "frac": round(cells / (kernel_ms * 1e-3) / 1e9 / full, 3),
+                "wave_cycle_fractions": pmc.get("wave_cycle_fractions"), "source": pmc["file"]}
+    return {"bound": "hbm", "kernel": kernel or LANE_KERNELS.get(int(routing[1]) & 15, "wavefront-per-pair kernels"),
+            "kernel_ms": round(kernel_ms, 4), "kernel_gcups": round(cells / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
+            "algorithmic_bytes": alg_bytes, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6),
+            # rows handed from strip to strip through HBM (16 B per column, lane and strip boundary: one
+            # store, one load): real traffic of multi-strip queries, not algorithmic
+            "strip_boundary_bytes": boundary_bytes,
+            "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc else None,
+            "valu_issue": valu}
+
+
+def strips_of(qlen, sw):
+    """Strips of a multi-strip query on the pair-table kernels (host.hip: strips of at most 52 rows; the
+    NW / HW / OV kernel prefers heights that divide the query)."""
+    if qlen <= 64:
+        return 1
+    if sw:
+        return max(2, -(-qlen // 52))
+    best = None
+    for rows in range(52, 30, -2):
+        ns = -(-qlen // rows)
+        if ns < 2 or (ns - 1) * rows >= qlen:
+            continue
+        cost = ns * (rows + 4) + (rows // 8 if ns * rows - qlen > 1 else 0)
+        if best is None or cost < best[0]:
+            best = (cost, ns)
+    return best[1] if best else 1
 
 
 def host_results(db, query, matrix, Q, N, L):
@@ -329,7 +438,22 @@ def cfg5_block(block, targets, length):
     return _data.AA20_CODES[rng.integers(0, 20, size=targets * length, dtype=np.uint8)]
 
 
-def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream):
+CFG5_CHECKSUM = 596_667_328   # sum of the 10M scores of BASELINE configs[4] (frozen at N = 1 in round 2)
+
+
+def cfg5_targets(lo, hi, length, n_total, block=100_000):
+    """Residues of the targets [lo, hi) of the cfg5 database."""
+    parts = []
+    for b in range(lo // block, (max(hi, lo + 1) - 1) // block + 1):
+        first = b * block
+        count = min(block, n_total - first)
+        piece = cfg5_block(b, count, length)
+        a, z = max(lo, first) - first, min(hi, first + count) - first
+        parts.append(piece[a * length:z * length])
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+
+
+def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream, collective):
     """BASELINE.json configs[4]: one 10M x 400 database (seed 3, generated in blocks of 100k
     targets), cut into contiguous shards of equal residue counts (pyopal_amd.shard.balanced_bounds,
     the reference's [start, end) chunks of src/pyopal/_align.py:150-170 balanced by residues), each
@@ -344,14 +468,7 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
     all_offsets = np.arange(n_total + 1, dtype=np.int64) * length
     bounds = balanced_bounds(all_offsets, world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    parts = []
-    for b in range(lo // block, (max(hi, lo + 1) - 1) // block + 1):
-        first = b * block
-        count = min(block, n_total - first)
-        piece = cfg5_block(b, count, length)
-        a, z = max(lo, first) - first, min(hi, first + count) - first
-        parts.append(piece[a * length:z * length])
-    residues = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    residues = cfg5_targets(lo, hi, length, n_total, block)
     n = hi - lo
     offsets = np.arange(n + 1, dtype=np.int64) * length
     t0 = time.time()
@@ -361,11 +478,11 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
     db.search_device_scores(query, matrix, outs[0].data_ptr(), stream, 3, 1, "sw")
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    pipe = OverlappedGather(outs, dst=0, on_device=on_device)
+    pipe = OverlappedGather(outs, dst=0, on_device=on_device, force=args.force_collective)
 
     def fence():
         pipe.drain()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -387,7 +504,7 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
     checksum = int(outs[pipe.last][:n].sum(dtype=torch.int64).item())
     stats = torch.tensor([elapsed, k_ms, float(checksum)], dtype=torch.float64,
                          device=f"cuda:{local_rank}" if on_device else "cpu")
-    if world > 1:
+    if collective:
         gathered = [torch.zeros_like(stats) for _ in range(world)] if rank == 0 else None
         dist.gather(stats, gathered, dst=0)
     else:
@@ -397,6 +514,28 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
         return None
     elapsed = max(float(g[0]) for g in gathered)
     cells = float(len(query)) * n_total * length
+    # Self-check of the sharded form (a wrong shard boundary, a gather slot in the wrong place or a rank
+    # that searched the wrong block would otherwise go unnoticed at N > 1): the whole-database checksum
+    # equals the one frozen at N = 1, and the first and last 1000 GATHERED scores of every shard equal a
+    # direct search of those targets (regenerated here; 2000 targets take the wavefront-per-pair kernel,
+    # not the kernel that produced the gathered scores).
+    total_checksum = int(sum(float(g[2]) for g in gathered))
+    if n_total == 10_000_000 and total_checksum != CFG5_CHECKSUM:
+        raise SystemExit(f"cfg5: checksum {total_checksum} over {world} shard(s), expected {CFG5_CHECKSUM}")
+    received = pipe.received[pipe.last] if collective else [outs[pipe.last]]
+    for r in range(world):
+        size = bounds[r + 1] - bounds[r]
+        k = min(1000, size)
+        if k == 0:
+            continue
+        mine = received[r][:size].cpu().numpy()
+        for a, z in ((bounds[r], bounds[r] + k), (bounds[r + 1] - k, bounds[r + 1])):
+            res = cfg5_targets(a, z, length, n_total, block)
+            sdb = _capi.DeviceDatabase(res, np.arange(z - a + 1, dtype=np.int64) * length, 24, device=local_rank)
+            direct = sdb.search(query, matrix, 3, 1, "score", "sw")["score"]
+            sdb.close()
+            if not np.array_equal(mine[a - bounds[r]:z - bounds[r]], direct):
+                raise SystemExit(f"cfg5: gathered scores of shard {r}, targets [{a}, {z}), differ from a direct search")
     return {
         "workload": f"sw_score q{len(query)} vs ONE {n_total}x{length} database (seed (3, block)), "
                     f"{world} residue-balanced contiguous shard(s), one gather of int32 scores to rank 0",
@@ -406,7 +545,8 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream)
         "ms_per_step": round(elapsed / args.cfg5_steps * 1e3, 3),
         "kernel_ms_per_rank": [round(float(g[1]), 3) for g in gathered],
         "targets_per_rank": [bounds[r + 1] - bounds[r] for r in range(world)],
-        "score_checksum": int(sum(float(g[2]) for g in gathered)),
+        "score_checksum": total_checksum,
+        "self_check": "checksum equals the N = 1 value; first and last 1000 gathered scores of every shard equal a direct search",
         "db_build_s_rank0": round(build_s, 2),
     }
 
@@ -436,19 +576,44 @@ def extras(db, query, matrix, Q, N, L):
     # longer queries on the headline database (the pair-table kernel strip by strip): scores and end locations
     rng = np.random.default_rng(11)
     longer = {}
+
+    def timed_leg(dbx, q, mode, algo, reps):
+        for _ in range(2):
+            dbx.search(q, matrix, 3, 1, mode, algo)
+        dbx.set_profiling(True)
+        dbx.last_kernel_time()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = dbx.search(q, matrix, 3, 1, mode, algo)
+        dt = (time.perf_counter() - t0) / reps
+        n_launch, k_total = dbx.last_kernel_time()
+        dbx.set_profiling(False)
+        return dt, (k_total / n_launch if n_launch else 0.0), _capi.DeviceDatabase.last_routing(), res
+
     for qlen in (150, 300):
         q = _data.random_protein(rng, qlen)
         row = {}
         for mode in ("score", "end"):
-            for _ in range(2):
-                db.search(q, matrix, 3, 1, mode, "sw")
-            t0 = time.perf_counter()
-            for _ in range(5):
-                db.search(q, matrix, 3, 1, mode, "sw")
-            dt = (time.perf_counter() - t0) / 5
-            row[mode] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(float(qlen) * N * L / dt / 1e9, 1)}
+            dt, k_ms, routing, _ = timed_leg(db, q, mode, "sw", 5)
+            cells = float(qlen) * N * L
+            row[mode] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(cells / dt / 1e9, 1)}
+            alg = float(N) * L + (12.0 if mode == "score" else 20.0) * N + qlen + 4 * 24 * 24
+            bnd = 16.0 * 64 * (-(-L // 4) * 4) * -(-N // 128) * (strips_of(qlen, True) - 1) if (routing[1] & 15) == 6 else None
+            row[mode]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"q{qlen}_sw" if mode == "score" else None, bnd)
         longer[f"q{qlen}"] = row
     out["longer_queries_sw"] = longer
+    # BASELINE configs[2]: Smith-Waterman with full alignments on the headline database
+    if (N, L) == (1_000_000, 300):
+        dt, k_ms, routing, res = timed_leg(db, query, "full", "sw", 3)
+        ops = int(res["aln_off"][-1])
+        cells = float(Q) * N * L
+        alg = float(N) * L + 12.0 * N + 16.0 * N + ops + Q + 4 * 24 * 24
+        roof = leg_roofline(dt * 1e3, cells, alg, routing, None,
+                            kernel="pipeline: interseq_pair_biased_kernel<.., true> (end pass), perpair_kernel (start cells, "
+                                   "directions), walk_kernel, gather_ops_kernel; kernel_ms = wall time of the whole call")
+        out["cfg3_full"] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(cells / dt / 1e9, 1),
+                            "end_pass_kernel_ms": round(k_ms, 4), "alignment_operations": ops, "roofline": roof}
+        del res
     # BASELINE configs[3] as written: 2000-aa query vs 100k x 2000 PLUS the reference's 35 long targets
     # (1000 ... 35000 residues: the ones that really leave 16 bits), every algorithm, scores
     if (N, L) == (1_000_000, 300):
@@ -460,13 +625,14 @@ def extras(db, query, matrix, Q, N, L):
         cells = 2000.0 * float(off[-1])
         cfg4 = {}
         for algo in ("nw", "hw", "ov", "sw"):
-            cdb.search(q, matrix, 3, 1, "score", algo)
-            t0 = time.perf_counter()
-            for _ in range(2):
-                cdb.search(q, matrix, 3, 1, "score", algo)
-            dt = (time.perf_counter() - t0) / 2
+            dt, k_ms, routing, _ = timed_leg(cdb, q, "score", algo, 3)
             cfg4[algo] = {"ms": round(dt * 1e3, 1), "host_results_gcups": round(cells / dt / 1e9, 1),
-                          "targets_on_the_int32_kernel": int(_capi.DeviceDatabase.last_routing()[0])}
+                          "targets_on_the_int32_kernel": int(routing[0])}
+            n_t = len(lengths)
+            alg = float(off[-1]) + 12.0 * n_t + 2000 + 4 * 24 * 24
+            packed_cols = 2000.0 * 782      # groups of 128 targets x columns, the 33 longest targets aside
+            bnd = 16.0 * 64 * packed_cols * (strips_of(2000, algo == "sw") - 1) if (routing[1] & 15) in (6, 7) else None
+            cfg4[algo]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"cfg4_{algo}" if algo in ("nw", "sw") else None, bnd)
         cdb.close()
         out["cfg4_with_tail"] = cfg4
     return out

@@ -223,15 +223,21 @@ class DeviceDatabase:
 
     def search(self, query: np.ndarray, matrix: np.ndarray, gap_open: int = 3, gap_extend: int = 1,
                mode: str = "score", algorithm: str = "sw", start: int = 0,
-               end: typing.Optional[int] = None) -> typing.Dict[str, typing.Any]:
-        """miopalSearch with numpy outputs (same keys as tests/_oracle.search)."""
+               end: typing.Optional[int] = None,
+               score_out: typing.Optional[np.ndarray] = None) -> typing.Dict[str, typing.Any]:
+        """miopalSearch with numpy outputs (same keys as tests/_oracle.search). ``score_out``: an
+        int32 array of end - start entries to receive the scores (a caller that re-uses its result
+        array; when it is pinned, device-visible host memory the kernel writes into it directly)."""
         end = self.count if end is None else min(end, self.count)
         n = max(end - start, 0)
         q = np.ascontiguousarray(query, dtype=np.uint8)
         S = np.ascontiguousarray(matrix, dtype=np.int32)
         st = SEARCH[mode]
+        if score_out is not None and (score_out.dtype != np.int32 or score_out.shape != (n,) or
+                                      not score_out.flags.c_contiguous):
+            raise ValueError("score_out must be a contiguous int32 array with one entry per target of the slice")
         # the C side writes every entry of its outputs (locations of empty alignments are -1)
-        out = {"score": np.empty(n, dtype=np.int32)}
+        out = {"score": score_out if score_out is not None else np.empty(n, dtype=np.int32)}
         et = eq = s_t = s_q = aoff = None
         ops_ptr = ctypes.c_void_p()
         if st >= 1:

@@ -56,6 +56,11 @@ struct InterseqArgs {
     int stripAbortAt;          //   the view is redone by the next rung anyway (it adds the same to *stripGaveUp)
     int* stripGaveUp;          //   = the overflow counter the host reads after the scatter
     int batchGroups;           // strips kernel: groups a workgroup sweeps side by side (1..12; fewer when the groups are few)
+    // one-strip biased Smith-Waterman kernel, scores only: results straight into database order (no view-order
+    // array, no scatter kernel); directOut may be pinned host memory (miopalSearch: no D2H copy either)
+    int32_t* directOut;        // already offset by - sliceStart: entry directIds[view position]; null: a.score
+    const int32_t* directIds;  // view position -> database index
+    int directN;               // view positions that hold a target
     int stripSpinCap;          // strips kernels: polls (x s_sleep) before a unit gives up on the strip above; 0 = the default
     int faultUnit1;            // strips kernels, test hook: unit (this - 1) behaves as if it had died; 0 = none
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4

@@ -201,6 +201,7 @@ struct Workspace {
     // (tens of milliseconds on fresh memory), a pinned bounce buffer does not.
     void* pinned = nullptr;
     size_t pinnedCap = 0, pinnedUsed = 0;
+    uint64_t stagingGeneration = 0;   // moves whenever the staging buffer is drained (its contents are void then)
     struct Pending { void* dst; size_t off, bytes; };
     std::vector<Pending> pending;
     std::vector<int32_t> hostScratchA, hostScratchB;  // per-target host arrays of a full search
@@ -241,6 +242,7 @@ struct Workspace {
         for (const Pending& p : pending) copyOut(p.dst, (const char*)pinned + p.off, p.bytes);
         pending.clear();
         pinnedUsed = 0;
+        ++stagingGeneration;
         return 0;
     }
     // A search that fails after stageDownload() leaves entries that point at the caller's (or the
@@ -251,6 +253,7 @@ struct Workspace {
         if (aux) (void)hipStreamSynchronize(aux);
         pending.clear();
         pinnedUsed = 0;
+        ++stagingGeneration;
     }
     // room for `bytes` more in the staging buffer (drains it, and grows it, when needed)
     int reserveStaging(size_t aligned) {
@@ -1155,6 +1158,12 @@ struct Search {
     int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
     int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
+    // miopalSearch: a pinned, device-visible buffer the scores may be written to directly (the one-strip
+    // Smith-Waterman fast path scatters into it from the kernel); wroteHost says that it was used
+    int32_t* hostScoreOut = nullptr;
+    uint64_t hostScoreGeneration = 0;   // of the staging buffer when hostScoreOut was reserved in it
+    bool hostScoreIsCallers = false;    // hostScoreOut is the caller's own pinned array
+    bool wroteHost = false;
     bool besidePersistent = false;    // the side jobs of this pass run beside a strips kernel (persistent, one workgroup per CU)
     // a score pass that starts over (refused launch, declined probe) has already put its side jobs on
     // the side stream: they are not enqueued twice, and the join still waits for them
@@ -1789,6 +1798,7 @@ struct Search {
             // int32 kernel on a side stream BESIDE the packed kernel; packed targets that need
             // the int32 kernel are redone after it, because both write the same result slots
             bool forked = sideForked;
+            bool directScatter = false;   // the packed kernel wrote database order itself
             if (!sideDone.empty()) {
                 sideJobs.erase(std::remove_if(sideJobs.begin(), sideJobs.end(), [&](const PairJob& j) {
                                    return std::binary_search(sideDone.begin(), sideDone.end(), j.out);
@@ -2035,6 +2045,24 @@ struct Search {
                     const bool uniform = (int64_t)shortest * 5 >= (int64_t)longest * 4;
                     ia.tailThrottle = (tt ? tt[0] == '1' : uniform) ? (ia.nGroups + blocks * 4 - 1) / (blocks * 4) : 0;
                 }
+                // Headline fast path: one strip, Smith-Waterman scores, no lane can leave its range, nothing
+                // else writes the results (no side jobs, no skipped groups, no windows): the kernel writes
+                // database order itself - into the caller's device buffer, or for miopalSearch into the
+                // pinned host buffer the results leave from (no scatter kernel, no device-to-host copy).
+                if (biased && !locate && !mayOverflow && overlap == 0 && !forked && sideJobs.empty() && jobs.empty() &&
+                    firstGroup == 0 && packedSkip == 0 && !getenv("MIOPAL_NO_DIRECT_SCATTER")) {
+                    int32_t* target = d_score;
+                    if (hostScoreOut && (hostScoreIsCallers || hostScoreGeneration == ws->stagingGeneration) &&
+                        !getenv("MIOPAL_NO_HOST_SCATTER")) {
+                        target = hostScoreOut;
+                        wroteHost = true;
+                    }
+                    ia.directOut = target - start;
+                    ia.directIds = view->d_ids;
+                    ia.directN = view->nPacked;
+                    ia.overflow = nullptr;
+                    directScatter = true;
+                }
                 const PairFlavour pf = globalPair ? kPairGlobalBiased : biased ? kPairSwBiased : halfFloat ? kPairSwHalf : kPairSwInt16;
                 g_lastRouting[1] = 2 + (int)pf;
                 // the biased kernel exists for every even number of rows: no padding rows to 8
@@ -2054,6 +2082,11 @@ struct Search {
                     if (getenv("MIOPAL_VERBOSE"))
                         fprintf(stderr, "miopal: pair-table kernel refused (%s), using the general kernel\n",
                                 hipGetErrorString(pe));
+                    if (directScatter) {   // (the general kernel writes view order)
+                        directScatter = wroteHost = false;
+                        ia.directOut = nullptr;
+                        ia.overflow = (uint8_t*)vo;
+                    }
                     HIP_TRY(launchInterseq(ia, rows, waves, flavour, locate, stream));
                 }
             } else {
@@ -2075,7 +2108,7 @@ struct Search {
                                            view->d_segStart, nScatter, start, (unsigned long long*)keys,
                                            mayOverflow ? (int32_t*)ct : nullptr, stream, keyBias));
                 HIP_TRY(launchDecodeKeys((const unsigned long long*)keys, (int)n, d_score, d_endI, d_endJ, stream, keyBias));
-            } else {
+            } else if (!directScatter) {
                 HIP_TRY(launchScatter(ia.score + packedSkip, (const uint8_t*)vo + packedSkip, view->d_ids + packedSkip,
                                       nScatter, start, d_score, mayOverflow ? (int32_t*)ct : nullptr, overlap > 0,
                                       stream));
@@ -2513,8 +2546,41 @@ static int searchImpl(MiopalDb* db, const unsigned char* query, int queryLength,
         RC_TRY(ws->get(kEndI, (size_t)n * sizeof(int32_t), &pi));
         RC_TRY(ws->get(kEndJ, (size_t)n * sizeof(int32_t), &pj));
     }
+    // scores of a plain score search may leave the kernel straight for the pinned staging buffer
+    size_t hostOff = 0;
+    const size_t hostBytes = ((size_t)n * sizeof(int32_t) + 255) & ~(size_t)255;
+    bool callerPinned = false;
+    if (searchType == OPAL_SEARCH_SCORE) {
+        // A caller whose result array is itself pinned, device-visible host memory (hipHostMalloc,
+        // hipHostRegister, a pinned torch tensor) gets the scores written into it by the kernel: no
+        // bounce buffer, no copy on the host.
+        hipPointerAttribute_t attr;
+        if (!getenv("MIOPAL_NO_CALLER_PINNED") && hipPointerGetAttributes(&attr, score) == hipSuccess &&
+            attr.type == hipMemoryTypeHost && attr.devicePointer != nullptr) {
+            s.hostScoreOut = (int32_t*)attr.devicePointer;
+            s.hostScoreIsCallers = true;
+            callerPinned = true;
+        } else {
+            (void)hipGetLastError();   // (an ordinary pointer is "invalid value" to the runtime)
+            // (room for the pass's own small uploads behind it, so that nothing drains or reallocates the
+            // buffer before the kernel is launched; if it happens all the same the generation tells)
+            RC_TRY(ws->reserveStaging(hostBytes + (1u << 20)));
+            hostOff = ws->pinnedUsed;
+            ws->pinnedUsed += hostBytes;
+            s.hostScoreOut = (int32_t*)((char*)ws->pinned + hostOff);
+            s.hostScoreGeneration = ws->stagingGeneration;
+        }
+    }
     RC_TRY(s.scorePass((int32_t*)ps, (int32_t*)pi, (int32_t*)pj));
-    RC_TRY(ws->stageDownload(score, ps, (size_t)n * sizeof(int)));
+    if (s.wroteHost && callerPinned) {
+        // (nothing to copy: visible to the host once the stream has drained, below)
+    } else if (s.wroteHost) {
+        if (s.hostScoreGeneration != ws->stagingGeneration)
+            return fail(MIOPAL_ERR_INTERNAL, "the staging buffer was drained under a kernel that writes to it");
+        ws->pending.push_back({score, hostOff, (size_t)n * sizeof(int32_t)});
+    } else {
+        RC_TRY(ws->stageDownload(score, ps, (size_t)n * sizeof(int)));
+    }
     if (wantEnd) {
         RC_TRY(ws->stageDownload(endQuery, pi, (size_t)n * sizeof(int)));
         RC_TRY(ws->stageDownload(endTarget, pj, (size_t)n * sizeof(int)));

@@ -1304,6 +1304,14 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
         }
         const int lo = (int)(best & 0xffffu) >> kBits, hi = (int)(best >> 16) >> kBits;
         const size_t base = (size_t)g * kGroupTargets;
+        if (!LOC && a.directOut) {
+            // database order at once (the host has made sure that no lane can leave its range and that
+            // nothing else writes these results): no view-order array, no scatter kernel
+            const int posA = (int)base + lane, posB = posA + kLanes;
+            if (posA < a.directN) a.directOut[a.directIds[posA]] = lo;
+            if (posB < a.directN) a.directOut[a.directIds[posB]] = hi;
+            continue;
+        }
         a.score[base + lane] = lo;
         a.score[base + kLanes + lane] = hi;
         if constexpr (LOC) {

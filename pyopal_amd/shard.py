@@ -57,7 +57,7 @@ class OverlappedGather:
     rehearsals) tensors go through host copies.
     """
 
-    def __init__(self, buffers, dst: int = 0, on_device: bool = True):
+    def __init__(self, buffers, dst: int = 0, on_device: bool = True, force: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -69,7 +69,9 @@ class OverlappedGather:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.pending = [None] * len(self.buffers)
         self.received = [None] * len(self.buffers)
-        if self.world > 1 and self.rank == dst:
+        # (force: gather even in a group of one rank - the rehearsal of the N > 1 path on one GPU)
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        if self.active and self.rank == dst:
             like = self.buffers[0] if on_device else self.buffers[0].cpu()
             self.received = [[torch.empty_like(like) for _ in range(self.world)] for _ in self.buffers]
         self._next = 0
@@ -86,7 +88,7 @@ class OverlappedGather:
         return b, self.buffers[b]
 
     def submit(self, b: int) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         tensor = self.buffers[b] if self.on_device else self.buffers[b].cpu()
         self.pending[b] = self._dist.gather(tensor, self.received[b], dst=self.dst, async_op=True)

@@ -32,13 +32,44 @@ def test_bench_line_small_workload():
     assert line["value"] > cpu["value"]
     # what the line says about itself: the host-visible form beside `value`, an honest CPU leg,
     # PMC-derived numbers only for the build they were measured on
-    assert line["value_host_results"] and line["value_host_results"] <= line["value"] * 1.05
-    assert "scores left in HBM" in line["config"]["workload"]
+    # `value` at N = 1 is the host-visible form (blocking call, scores in the caller's pinned host array);
+    # the HBM-resident form and the pageable-array form stand beside it
+    assert line["value_device_results"] and line["value"] <= line["value_device_results"] * 1.05
+    assert line["value_host_results_pageable"] and line["value_host_results_pageable"] <= line["value"] * 1.05
+    assert "pinned host array" in line["config"]["workload"] and line["forced_collective"] is False
+    assert "lds" in roof
     assert cpu["value_one_thread"] > 0 and cpu["cpu_model"] and cpu["host_physical_cores"] >= cpu["cores"] >= 1
     assert roof["traffic"] is None    # 50k targets is not the profiled workload
     assert set(roof["valu_issue"]) >= {"achieved", "full_rate_peak", "frac", "cycles_per_instruction", "instructions_per_cell_pair"}
     strong = line["extras"]["cfg5_strong"]
     assert strong["scaling"] == "strong" and strong["gcups"] > 0 and sum(strong["targets_per_rank"]) == 250000
+    assert "self_check" in strong
+    # per-config rooflines of the secondary legs (the bound per config)
+    for row in line["extras"]["longer_queries_sw"].values():
+        for leg in row.values():
+            assert leg["roofline"]["bound"] == "hbm" and leg["roofline"]["kernel_ms"] > 0 and leg["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_forced_collective_on_one_gpu():
+    # the N > 1 path on the one GPU there is: a 1-rank nccl group under torch.distributed.run, RCCL's gather
+    # of device tensors behind the search (stream ordering, MIOPAL_RESERVE_CUS), all_reduce of the elapsed
+    # time, the self-check of the sharded cfg5 leg
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--targets", "50000", "--cfg5-targets", "250000", "--cfg5-steps", "2", "--force-collective"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["forced_collective"] is True and line["n_gpus"] == 1 and line["value"] > 0
+    assert "RCCL gather" in line["config"]["workload"]
+    assert line["extras"]["cfg5_strong"]["gcups"] > 0
 
 
 def test_bench_refuses_to_run_without_gpu():

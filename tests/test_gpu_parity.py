@@ -606,3 +606,39 @@ def test_long_pairs_one_wavefront_per_strip(capi, qlen, monkeypatch):
             old, _ = run_both(capi, query, res, off, B62, 11, 1, mode, algo)
             monkeypatch.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
             compare(old, ref, mode, f"strip after strip {algo}/{mode}/Q={qlen}")
+
+
+def test_scores_written_by_the_kernel_into_database_order(capi):
+    # headline fast path (one strip, Smith-Waterman scores, nothing can leave its range): the kernel
+    # scatters into database order itself - into the pinned staging buffer of miopalSearch, into a
+    # caller's re-used array, into a caller's PINNED array (no copy at all) - for whole databases and
+    # slices, ragged groups, and with the switches that restore the scatter kernel
+    import os
+    import torch
+    rng = np.random.default_rng(404)
+    query = _oracle.encode(_data.README_QUERY)
+    res, off = _data.random_db(rng, rng.integers(1, 400, size=9000))
+    want = _oracle.search_parallel(query, res, off, B62, 3, 1, "score", "sw")["score"]
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        pinned = torch.empty(9000, dtype=torch.int32).pin_memory().numpy()
+        plain = np.empty(9000, dtype=np.int32)
+        for switch in (None, "MIOPAL_NO_HOST_SCATTER", "MIOPAL_NO_DIRECT_SCATTER", "MIOPAL_NO_CALLER_PINNED"):
+            if switch:
+                os.environ[switch] = "1"
+            try:
+                for lo, hi in ((0, 9000), (1, 9000), (4000, 4001), (137, 8999)):
+                    got = db.search(query, B62, 3, 1, "score", "sw", lo, hi)["score"]
+                    np.testing.assert_array_equal(got, want[lo:hi], err_msg=f"{switch} [{lo},{hi})")
+                    for buf in (plain, pinned):
+                        buf[:] = -7
+                        db.search(query, B62, 3, 1, "score", "sw", lo, hi, score_out=buf[: hi - lo])
+                        np.testing.assert_array_equal(buf[: hi - lo], want[lo:hi], err_msg=f"{switch} [{lo},{hi}) into a buffer")
+                        assert (buf[hi - lo:] == -7).all()
+            finally:
+                if switch:
+                    del os.environ[switch]
+        with pytest.raises(ValueError):
+            db.search(query, B62, 3, 1, "score", "sw", score_out=np.empty(5, dtype=np.int32))
+    finally:
+        db.close()
