@@ -1549,7 +1549,11 @@ struct Search {
             while (maxRows >= 32 && !interseqPairFits(maxRows, A + 1)) maxRows -= 2;
             const int64_t pos = std::max(maxScore, 0);
             const int64_t zeroG = 0x0400 + 3 * (int64_t)open + ((int64_t)Q + 4) * ext + std::max(0, -minScore);
-            const int64_t above = r.topGap ? (int64_t)Q * (pos + ext) : (int64_t)Q * pos + kLocMaxShift;
+            // (the cells of a strip are on anti-diagonally shifted scales - row r carries r ext more - and H is
+            // kept open - ext below its plain form: one strip's rows and an opening more on either side; the
+            // kernel's zero is the one-strip kernel's, which has this room below it: 3 open cover 2)
+            const int64_t above = (r.topGap ? (int64_t)Q * (pos + ext) : (int64_t)Q * pos + kLocMaxShift) +
+                                  ((int64_t)kPairStripsMaxRows + 4) * ext + open;
             const bool inRange = zeroG + above + 5 * (int64_t)ext + pos < 0x7C00 && 5 * (int64_t)ext <= kLocMaxShift &&
                                  minScore > kBiasedPad && (r.topGap ? open >= ext : true);
             if (!oneStrip && maxRows >= 32 && Q > 32 && inRange && !(noPair && noPair[0] == '1')) {

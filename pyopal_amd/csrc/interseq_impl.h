@@ -80,6 +80,10 @@ static __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, u
         __builtin_bit_cast(f16x2, c));
     return __builtin_bit_cast(uint32_t, r);
 }
+static __device__ __forceinline__ uint32_t pk_max2_f16(uint32_t a, uint32_t b) {
+    f16x2 r = __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
 static __device__ __forceinline__ uint32_t dup16(int v) { return ((uint32_t)v & 0xffffu) * 0x00010001u; }
 
 // ---- arithmetic flavours --------------------------------------------------------
@@ -2134,7 +2138,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
         if (u >= nBatches * nStrips) break;
         const int s = u / nBatches, b = u - s * nBatches;   // strip-major (see interseq_pair_strips_kernel)
         if (s != tableStrip) {
-            // (s + ext) of both targets as one integer; padding symbol / rows add nothing
+            // s'' = s + 2 ext + c = s + ext + open of both targets as one integer (the diagonal step crosses
+            // two anti-diagonals, and H is kept in its stored form, c = open - ext below its plain form);
+            // padding symbol / rows add c: the pattern of a padding cell is the one of its diagonal neighbour
             const int16_t* gp = a.profile + s * R;
             uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
             const int total = nSym * nSym * R;
@@ -2142,8 +2148,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                 const int row = idx / R, r = idx - row * R;
                 const int tA = row / nSym, tB = row - tA * nSym;
                 const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
-                const int sA = vA == kBiasedPadScore ? 0 : vA + ext;
-                const int sB = vB == kBiasedPadScore ? 0 : vB + ext;
+                const int sA = vA == kBiasedPadScore ? open - ext : vA + ext + open;
+                const int sB = vB == kBiasedPadScore ? open - ext : vB + ext + open;
                 pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
             }
             tableStrip = s;
@@ -2204,14 +2210,16 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                 // all 2 R of them in scalar registers first, and spills hundreds)
                 const int i0 = s * R;
                 int one = open + i0 * ext, many = (i0 + 1) * open;
-                asm volatile("" : "+v"(one), "+v"(many));
+                int rowShift = 0;                                      // r ext: the anti-diagonal part of the scale
+                asm volatile("" : "+v"(one), "+v"(many), "+v"(rowShift));
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    const int left = leftGap ? -min(one, many) : 0;
-                    H[r] = both(zero - ext + left);                   // on column -1's scale
-                    E[r] = both(zero + left - open);                  // E[i][0] on column 0's scale
+                    const int left = (leftGap ? -min(one, many) : 0) + rowShift;
+                    H[r] = both(zero - ext + left - (open - ext));    // stored form, on the scale of (r, -1)
+                    E[r] = both(zero + left - open);                  // E[i][0], plain form on the scale of (r, 0)
                     one += ext;
                     many += open;
+                    rowShift += ext;
                 }
             }
             constexpr int kRowsAhead = MIOPAL_STRIP_ROWS_AHEAD;
@@ -2221,7 +2229,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
             // H of the row above at column j - 1, on that column's scale: the left border of row s R - 1
             uint32_t hbPrev = 0u;
             if constexpr (kFromAbove) {
-                hbPrev = both(zero - ext + (leftGap ? borderGap(s * R - 1, open, ext) : 0));
+                // (stored form on the scale of (-1, -1): one row above the strip's row 0)
+                hbPrev = both(zero - ext + (leftGap ? borderGap(s * R - 1, open, ext) : 0) - ext - (open - ext));
 #pragma unroll
                 for (int x = 0; x < kRowsAhead; ++x) bq[x] = loadRow(min(x, lastCol));
             }
@@ -2267,8 +2276,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                         sigma += ext;
                         f = bq[0].y;                    // F entering the strip's first row, on this column's scale
                     } else {
-                        // row above the matrix: H[-1][j-1] on the previous column's scale, H[-1][j] on this one's
-                        dsum = both(sigma + topPrev) + score(0);
+                        // row above the matrix: H[-1][j-1] in stored form on the scale of (-1, j - 1), the F that
+                        // H[-1][j] opens in plain form on the scale of (0, j)
+                        dsum = both(sigma + topPrev - open) + score(0);
                         sigma += ext;
                         f = both(sigma + topHere - open);
                         asm volatile("" : "+v"(f));
@@ -2288,13 +2298,16 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                             if (r >= R) continue;
                             uint32_t dnext = 0;
                             if (r + 1 < R) dnext = H[r] + score(r + 1);
+                            // 2 integer adds + 1 max3 + 2 max: every cell (r, j) is on the scale zero + sigma(j) +
+                            // r ext, so extending either gap costs nothing, both open with hmo = h - c, and hmo is
+                            // at once the stored form of h that the next column's diagonal sum starts from
                             const uint32_t h = pk_max3_f16(dsum, E[r], f);
                             const uint32_t hmo = h - openMinusExt2;
-                            E[r] = pk_max3_f16(E[r], hmo, hmo);
+                            E[r] = pk_max2_f16(E[r], hmo);
                             asm volatile("" : "+v"(E[r]));
                             // (after the last row: what the strip below starts from)
-                            if (kToBelow || r + 1 < R) f = pk_max3_f16(f, hmo, hmo) - ext2;
-                            H[r] = h;
+                            if (kToBelow || r + 1 < R) f = pk_max2_f16(f, hmo);
+                            H[r] = hmo;
                             dsum = dnext;
                         }
                         asm volatile("" : "+v"(f), "+v"(dsum)::"memory");
@@ -2302,9 +2315,13 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                         for (int k = 1; k <= 4; ++k)
                             if (r4 * 4 + 3 + k < R) asm volatile("" : "+v"(H[r4 * 4 + 3 + k]));
                     }
-                    if constexpr (kToBelow)
-                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane), ((unsigned long long)f << 32) | H[R - 1],
+                    if constexpr (kToBelow) {
+                        // (row R of this strip is row 0 of the strip below, whose scale starts again at r = 0)
+                        const uint32_t down = both(R * ext);
+                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane),
+                                           ((unsigned long long)(f - down) << 32) | (H[R - 1] - down),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if constexpr (kFromAbove) {
                         hbPrev = bq[0].x;
 #pragma unroll
@@ -2317,7 +2334,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                         // tree of wave-uniform BRANCHES finds it (selects would be R hoisted scalar predicates).
                         uint32_t hq = H[R - 1];
                         if (rl != R - 1) hq = pickRow<0, R - 2>(H, rl);
-                        const int qA = (int)(hq & 0xffffu) - sigma, qB = (int)(hq >> 16) - sigma;
+                        // (stored form on the scale of (rl, j): true value = pattern - sigma - rl ext + c)
+                        const int back = sigma + rl * ext - (open - ext);
+                        const int qA = (int)(hq & 0xffffu) - back, qB = (int)(hq >> 16) - back;
                         if (region == kLastCell) {
                             if (j == lenA - 1) { runA = qA; if (LOC) colA = j; }
                             if (j == lenB - 1) { runB = qB; if (LOC) colB = j; }
@@ -2338,17 +2357,24 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                             // column loop into scalar register pairs.)
                             int rows = kToBelow ? R : rl + 1;
                             if (!kToBelow) asm volatile("" : "+v"(rows));
+                            // (row r is on the scale of column j plus r ext: taken off with a running offset)
+                            uint32_t off = 0u;
                             auto rowValue = [&](int r) -> uint32_t {
-                                if (!kToBelow && r > 0) return r < rows ? H[r] : H[0];
-                                return H[r];
+                                uint32_t v = H[r];
+                                if (!kToBelow && r > 0) v = r < rows ? H[r] : H[0] + off;
+                                return v - off;
                             };
-                            uint32_t m2 = rowValue(0);
+                            uint32_t m2 = H[0];
 #pragma unroll
-                            for (int r = 1; r + 1 < R; r += 2) m2 = pk_max3_f16(m2, rowValue(r), rowValue(r + 1));
-                            if ((R & 1) == 0) m2 = pk_max3_f16(m2, rowValue(R - 1), rowValue(R - 1));
+                            for (int r = 1; r < R; ++r) {
+                                off += ext2;
+                                asm volatile("" : "+v"(off));
+                                m2 = pk_max2_f16(m2, rowValue(r));
+                            }
                             const int mA = (int)(m2 & 0xffffu), mB = (int)(m2 >> 16);
-                            if (lastA) cbA = mA - sigma;
-                            if (lastB) cbB = mB - sigma;
+                            const int back = sigma - (open - ext);
+                            if (lastA) cbA = mA - back;
+                            if (lastB) cbB = mB - back;
                             if constexpr (LOC) {
                                 // first row that holds the maximum of its half
                                 int ia = 0, ib = 0;
@@ -2357,7 +2383,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                                     const uint32_t d = rowValue(r) ^ m2;
                                     if ((d & 0xffffu) == 0) ia = r;
                                     if ((d >> 16) == 0) ib = r;
-                                    asm volatile("" : "+v"(ia), "+v"(ib));
+                                    asm volatile("" : "+v"(ia), "+v"(ib), "+v"(off));
+                                    off -= ext2;
                                 }
                                 if (lastA) crowA = s * R + ia;
                                 if (lastB) crowB = s * R + ib;
