@@ -1705,8 +1705,9 @@ struct Search {
                 !sw && nStrips == 1 && !globalPairRefused && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
                 interseqPairFits(pairRows, nSym) && minScore > kBiasedPad && (r.topGap ? open >= ext : true) &&
                 5 * (int64_t)ext <= kLocMaxShift &&
+                // (+ the strip's rows and an opening: the cells are on anti-diagonally shifted scales, round 3)
                 globalZero + (int64_t)Q * (std::max(maxScore, 0) + ext) + kLocMaxShift + 5 * (int64_t)ext +
-                        std::max(maxScore, 0) < 0x7C00;
+                        std::max(maxScore, 0) + ((int64_t)Q + 4) * ext + open < 0x7C00;
             if (globalPair || globalStrips) {
                 // only empty targets (closed forms of the border) are left to the int32 kernel
                 for (int e = view->nPacked - 1; e >= firstPos && dbLen(db, view->ids[e]) == 0; --e)

@@ -1816,9 +1816,11 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
     const bool topGap = a.topGap, leftGap = a.leftGap;
     const int region = a.region;
     const bool locate = a.endI != nullptr;
-    const uint32_t ext2 = both(ext), openMinusExt2 = both(open - ext);
+    const uint32_t openMinusExt2 = both(open - ext);
 
-    // table: (s + ext) of both targets as one integer; padding symbol / rows add nothing
+    // table: s'' = s + 2 ext + c = s + ext + open of both targets as one integer (round 3: every cell (r, j) is
+    // on the scale zero + sigma(j) + r ext, H kept c = open - ext below its plain form: 2 integer adds + 3
+    // max per cell pair, see interseq_pair_global_strips_kernel); padding symbol / rows add c
     {
         const int16_t* gp = a.profile;
         uint32_t* pw = reinterpret_cast<uint32_t*>(pairs);
@@ -1827,8 +1829,8 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
             const int row = idx / R, r = idx - row * R;
             const int tA = row / nSym, tB = row - tA * nSym;
             const int vA = gp[tA * a.qPad + r], vB = gp[tB * a.qPad + r];
-            const int sA = vA == kBiasedPadScore ? 0 : vA + ext;
-            const int sB = vB == kBiasedPadScore ? 0 : vB + ext;
+            const int sA = vA == kBiasedPadScore ? open - ext : vA + ext + open;
+            const int sB = vB == kBiasedPadScore ? open - ext : vB + ext + open;
             pw[row * (SLOTS * 4) + r] = (uint32_t)(sB * 65536 + sA);
         }
     }
@@ -1882,14 +1884,15 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
             int zeroHere = zero, openHere = open, extHere = ext;
             asm volatile("" : "+s"(zeroHere), "+s"(openHere), "+s"(extHere));
             // H[r][-1]: one gap of r + 1 residues or r + 1 one-residue gaps (borderGap), as running sums
-            int one = openHere, many = openHere;
+            int one = openHere, many = openHere, rowShift = 0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int left = leftGap ? -min(one, many) : 0;
-                H[r] = both(zeroHere - extHere + left);                   // on column -1's scale
-                E[r] = both(zeroHere + left - openHere);                  // E[r][0] on column 0's scale
+                const int left = (leftGap ? -min(one, many) : 0) + rowShift;
+                H[r] = both(zeroHere - extHere + left - (openHere - extHere));   // stored form, scale of (r, -1)
+                E[r] = both(zeroHere + left - openHere);                  // E[r][0], plain form, scale of (r, 0)
                 one += extHere;
                 many += openHere;
+                rowShift += extHere;
             }
         }
         uint2 cur = pack[lane];
@@ -1926,7 +1929,8 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
                 // row above the strip: H[-1][j-1] on the previous column's scale, H[-1][j] on this one's
                 const int topPrev = (j == 0 || !topGap) ? 0 : borderGap(j - 1, open, ext);
                 const int topHere = topGap ? borderGap(j, open, ext) : 0;
-                uint32_t dsum = both(sigma + topPrev) + score(0);
+                // (H[-1][j-1] in stored form on the scale of (-1, j - 1))
+                uint32_t dsum = both(sigma + topPrev - open) + score(0);
                 sigma += ext;
                 uint32_t f = both(sigma + topHere - open);      // F entering row 0
                 asm volatile("" : "+v"(f));
@@ -1945,12 +1949,12 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
                         if (r + 1 < R) dnext = H[r] + score(r + 1);
                         const uint32_t h = pk_max3_f16(dsum, E[r], f);
                         const uint32_t hmo = h - openMinusExt2;
-                        E[r] = pk_max3_f16(E[r], hmo, hmo);
+                        E[r] = pk_max2_f16(E[r], hmo);
                         // (here, not whenever the scheduler likes: E is off the critical path, and the R
                         // deferred updates would each hold on to their hmo)
                         asm volatile("" : "+v"(E[r]));
-                        if (r + 1 < R) f = pk_max3_f16(f, hmo, hmo) - ext2;
-                        H[r] = h;
+                        if (r + 1 < R) f = pk_max2_f16(f, hmo);
+                        H[r] = hmo;
                         dsum = dnext;
                     }
                     // pins the schedule: no ds_read and none of the NEXT blocks' diagonal sums (they only
@@ -1963,7 +1967,9 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
                 }
                 // ---- answers: the last query row is row R - 1 or R - 2 (R = Q rounded up to even)
                 const uint32_t hq = (Q & 1) ? H[R >= 2 ? R - 2 : 0] : H[R - 1];
-                const int qA = (int)(hq & 0xffffu) - sigma, qB = (int)(hq >> 16) - sigma;
+                // (stored form on the scale of (Q - 1, j): true value = pattern - sigma - (Q - 1) ext + c)
+                const int back = sigma + (Q - 1) * ext - (open - ext);
+                const int qA = (int)(hq & 0xffffu) - back, qB = (int)(hq >> 16) - back;
                 if (region == kLastCell) {
                     if (j == lenA - 1) { runA = qA; colA = j; }
                     if (j == lenB - 1) { runB = qB; colB = j; }
@@ -1977,19 +1983,24 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
                     if (region == kLastRowCol && __builtin_amdgcn_ballot_w64(lastA || lastB) != 0) {
                         // some lane is on its target's last column: first maximum over the query rows
                         int mA = INT32_MIN, mB = INT32_MIN, ia = 0, ib = 0;
+                        int off = (R - 1) * ext;   // row r is on the scale of column j plus r ext
+                        asm volatile("" : "+v"(off));
 #pragma unroll
                         for (int r = R - 1; r >= 0; --r) {
                             // (rows beyond the query: only row R - 1, when Q is odd; one test, not one
                             // per row - per-row predicates would be hoisted into a hundred SGPRs)
-                            if (r == R - 1 && (Q & 1)) continue;
-                            const int hA = (int)(H[r] & 0xffffu), hB = (int)(H[r] >> 16);
-                            if (hA >= mA) { mA = hA; ia = r; }
-                            if (hB >= mB) { mB = hB; ib = r; }
+                            if (!(r == R - 1 && (Q & 1))) {
+                                const int hA = (int)(H[r] & 0xffffu) - off, hB = (int)(H[r] >> 16) - off;
+                                if (hA >= mA) { mA = hA; ia = r; }
+                                if (hB >= mB) { mB = hB; ib = r; }
+                            }
+                            off -= ext;
                             // (row by row: the scheduler would otherwise unpack all 2 R halves up front)
-                            asm volatile("" : "+v"(mA), "+v"(mB));
+                            asm volatile("" : "+v"(mA), "+v"(mB), "+v"(off));
                         }
-                        if (lastA) { cbA = mA - sigma; crowA = ia; }
-                        if (lastB) { cbB = mB - sigma; crowB = ib; }
+                        const int back = sigma - (open - ext);
+                        if (lastA) { cbA = mA - back; crowA = ia; }
+                        if (lastB) { cbB = mB - back; crowB = ib; }
                     }
                 }
             }
