@@ -57,6 +57,15 @@ int miopalDbCreate(MiopalDb** out, const unsigned char* const* sequences, const 
 int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int64_t* offsets,
                        int64_t count, int alphabetLength, int device);
 
+/*
+ * A new handle holding the targets `indices[0 .. count)` of `parent` (any order, repeats allowed), on
+ * the parent's device: the residues are gathered from the parent's resident copy on the device, nothing
+ * is uploaded. What Database.mask / Database.extract need (src/pyopal/lib.pyx:694-778: subsets that
+ * share the parent's sequence buffers) - here the subset owns a device-side copy of its residues, so
+ * either handle may be destroyed first. The parent must not be destroyed during the call.
+ */
+int miopalDbCreateSubset(MiopalDb** out, const MiopalDb* parent, const int64_t* indices, int64_t count);
+
 void miopalDbDestroy(MiopalDb* db);
 
 /* opalSearchDatabase (include/opal.h) receives the whole database on every call; the library keeps

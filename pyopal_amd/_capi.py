@@ -44,7 +44,7 @@ EXPORTS = [
     "opalInitSearchResult", "opalSearchResultIsEmpty", "opalSearchResultSetScore",
     "opalSearchDatabase", "opalSearchDatabaseCharSW",
     # miopal.h
-    "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat",
+    "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat", "miopalDbCreateSubset",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalLastRouting", "miopalSearchResults", "miopalReleaseCaches",
@@ -96,6 +96,12 @@ def lib() -> ctypes.CDLL:
         L.miopalDbCreate.argtypes = [ctypes.POINTER(c_vp), c_vp, c_vp, c_i64, c_int, c_int]
         L.miopalDbCreateFlat.restype = c_int
         L.miopalDbCreateFlat.argtypes = [ctypes.POINTER(c_vp), c_vp, c_vp, c_i64, c_int, c_int]
+        L.miopalDbCreateSubset.restype = c_int
+        L.miopalDbCreateSubset.argtypes = [ctypes.POINTER(c_vp), c_vp, c_vp, c_i64]
+        L.miopalSelfTest.restype = c_int
+        L.miopalSelfTest.argtypes = [c_int]
+        L.miopalTestInjectFault.restype = None
+        L.miopalTestInjectFault.argtypes = [c_int, c_int, c_int]
         L.miopalDbDestroy.restype = None
         L.miopalDbDestroy.argtypes = [c_vp]
         for name in ("miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes"):
@@ -206,6 +212,23 @@ class DeviceDatabase:
     @property
     def handle(self):
         return self._h
+
+    def subset(self, indices) -> "DeviceDatabase":
+        """A new resident database holding the targets ``indices`` of this one, gathered on the device
+        from this one's residues (miopalDbCreateSubset: nothing crosses PCIe)."""
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        handle = ctypes.c_void_p()
+        rc = lib().miopalDbCreateSubset(ctypes.byref(handle), self._h, _ptr(idx) if len(idx) else None, len(idx))
+        raise_for(rc)
+        sub = DeviceDatabase.__new__(DeviceDatabase)
+        sub._h = handle
+        sub.count = len(idx)
+        lengths = np.diff(self.offsets)[idx] if len(idx) else np.zeros(0, dtype=np.int64)
+        sub.offsets = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=sub.offsets[1:])
+        sub.alphabet_length = self.alphabet_length
+        sub.device = self.device
+        return sub
 
     def close(self):
         if getattr(self, "_h", None):

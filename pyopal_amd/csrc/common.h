@@ -287,6 +287,9 @@ hipError_t launchScatterKeyed(const int32_t* viewScore, const int32_t* viewEndI,
 hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* score, int32_t* endI, int32_t* endJ,
                             hipStream_t stream, int scoreBias = 0);
 hipError_t launchFillInt32(int32_t* out, int n, int32_t value, hipStream_t stream);
+// subset of a resident database: dst[dstOff[k] ...] = src[srcStart[k] ...] for every sequence k (dstOff has n + 1 entries)
+hipError_t launchGatherSequences(const uint8_t* src, const int64_t* srcStart, const int64_t* dstOff, int64_t n,
+                                 uint8_t* dst, hipStream_t stream);
 // takeMax: several view positions (segments) may belong to one target; `out` starts at 0
 hipError_t launchScatter(const int32_t* viewScore, const uint8_t* viewOverflow, const int32_t* ids,
                          int nTargets, int64_t sliceStart, int32_t* out, int32_t* overflowCount,

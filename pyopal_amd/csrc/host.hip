@@ -1520,8 +1520,17 @@ struct Search {
                 int64_t totalChunks = 0;
                 for (int c : view->groupChunksHost) totalChunks += c;
                 const int64_t balanced = totalChunks * ns / ((int64_t)db->computeUnits * 12);
-                const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= balanced;
-                const bool enough = ((ns >= 16 || 2 * units >= 5 * (int64_t)db->computeUnits) && hidden) || getenv("MIOPAL_PAIR_STRIPS");
+                // (Round 3, with the wavefronts of a SIMD paced: measured again over 20k .. 2M targets, uniform,
+                // log-normal and bimodal lengths - tools/quick_routing_ab.py, profiles/r03_routing_ab.txt. The
+                // strips kernel wins from 1.5 units per CU on; its longest group may be as long as 1.2 balanced
+                // shares of a wavefront slot - the chain of that group is then about the whole launch - and with
+                // 16 strips or more the general kernel's rounds cost more than any chain.)
+                const bool hidden = view->nGroups > 0 && 5 * (int64_t)view->groupChunksHost[0] <= 6 * balanced;
+                // (with 16 strips or more a longest group of up to three balanced shares still pays; beyond that
+                // - 20k targets, a tenth of them thirty times as long as the rest - the chain of the longest
+                // group is the launch and the general kernel's pipeline over a workgroup's wavefronts is shorter)
+                const bool chainOk = view->nGroups > 0 && (int64_t)view->groupChunksHost[0] <= 3 * balanced;
+                const bool enough = ((ns >= 16 && chainOk) || (2 * units >= 3 * (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
                 if (enough && rowsP >= 32 && rowsP <= maxRows && band(rowsP) && (int64_t)(ns - 1) * rowsP < Q && ns <= 4096) {
                     stripRows = rowsP;
                     nStrips = ns;
@@ -1577,10 +1586,13 @@ struct Search {
                     int64_t totalChunks = 0;
                     for (int c : view->groupChunksHost) totalChunks += c;
                     const int64_t balanced = totalChunks * bestNs / ((int64_t)db->computeUnits * 12);
-                    const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= balanced;
+                    // (the general kernel's lanes are a third slower for these modes than this kernel's: a longest
+                    // group of up to 1.5 balanced shares still pays, and so does one unit per CU)
+                    const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= 3 * balanced;
                     // (the same two limits as the Smith-Waterman strips kernel: units enough to keep every
                     // CU on one strip for a while, the longest group short against the launch)
-                    const bool enough = ((bestNs >= 16 || 2 * units >= 5 * (int64_t)db->computeUnits) && hidden) || getenv("MIOPAL_PAIR_STRIPS");
+                    const bool chainOk = view->nGroups > 0 && (int64_t)view->groupChunksHost[0] <= 3 * balanced;
+                    const bool enough = ((bestNs >= 16 && chainOk) || (units >= (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
                     if (enough) {
                         stripRows = bestRows;
                         nStrips = bestNs;
@@ -1608,6 +1620,27 @@ struct Search {
             // windows of a segmented view are as short as a group of long targets can get
             if (overlap > 0) limit = std::max<int64_t>(limit, (segmentStride(overlap) + overlap + 3) / 4);
             while (firstGroup < view->nGroups && view->groupChunksHost[firstGroup] > limit) ++firstGroup;
+            // ... unless the groups above the limit ARE the search (round 3: a tenth of 500k targets thirty
+            // times as long as the rest - 391 groups of 3000 columns hold three quarters of the cells, all of
+            // them beyond 2.5 balanced shares: 50 560 targets on the int32 kernel, 7.7 ms for NW at Q = 53,
+            // 0.5 TCUPS). Rough costs of both ways: a wavefront sweeps a 4-column chunk of ~54 rows in about
+            // 7 us beside two others on its SIMD and 2.5 times faster alone - which is how the long groups at
+            // the head of the length-sorted hand-out end, the short ones long done; the int32 kernel fills
+            // about 1e12 cells a second beside the packed launch.
+            if (firstGroup > 0 && !getenv("MIOPAL_ALWAYS_SKIP")) {
+                const int rowsNow = stripRows ? stripRows : std::min(Q, kMaxStripRows);
+                const double rounds = stripRows ? 1.0 : (double)((nStrips + waves - 1) / waves);
+                const double tau = 7e-6 * rowsNow / 54.0 * rounds;
+                const double balancedAll = (double)total / (double)std::max<int64_t>(slots, 1) * (stripRows ? nStrips : 1);
+                int64_t skippedChunks = 0;
+                for (int g = 0; g < firstGroup; ++g) skippedChunks += view->groupChunksHost[g];
+                const double balancedRest = (double)(total - skippedChunks) / (double)std::max<int64_t>(slots, 1) * (stripRows ? nStrips : 1);
+                const double keep = std::max(balancedAll * tau, view->groupChunksHost[0] * tau / 2.5);
+                const double nextLongest = firstGroup < view->nGroups ? view->groupChunksHost[firstGroup] : 0;
+                const double side = (double)skippedChunks * 4.0 * kGroupTargets * (double)Q / 1e12;
+                const double skip = std::max({balancedRest * tau, nextLongest * tau / 2.5, side});
+                if (skip >= keep) firstGroup = 0;
+            }
             const int skipped = std::min(firstGroup * kGroupTargets, view->nPacked);
             for (int k = 0; k < skipped; ++k) queueWhole(sideJobs, view->ids[k]);
             balancedChunks = total / std::max<int64_t>(slots, 1);
@@ -2373,6 +2406,51 @@ int miopalDbCreateFlat(MiopalDb** out, const unsigned char* residues, const int6
     ResidueSource src;
     src.flat = residues;
     return createCommon(out, src, std::move(off), count, alphabetLength, device);
+    });
+}
+
+int miopalDbCreateSubset(MiopalDb** out, const MiopalDb* parent, const int64_t* indices, int64_t count) {
+    return guarded([&]() -> int {
+    if (!out) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null output handle");
+    *out = nullptr;
+    if (!parent) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null parent handle");
+    if (count < 0 || (count > 0 && !indices) || count >= INT32_MAX) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad subset");
+    std::vector<int64_t> offsets((size_t)count + 1, 0), srcStart((size_t)std::max<int64_t>(count, 1), 0);
+    for (int64_t k = 0; k < count; ++k) {
+        const int64_t id = indices[k];
+        if (id < 0 || id >= parent->count) return fail(MIOPAL_ERR_BAD_ARGUMENT, "subset index %lld outside the database", (long long)id);
+        srcStart[(size_t)k] = parent->offsets[(size_t)id];
+        offsets[(size_t)k + 1] = offsets[(size_t)k] + (parent->offsets[(size_t)id + 1] - parent->offsets[(size_t)id]);
+    }
+    std::unique_ptr<MiopalDb> db;
+    RC_TRY(newHandle(&db, parent->device));
+    db->alphabet = parent->alphabet;
+    db->count = count;
+    db->total = offsets[(size_t)count];
+    for (int64_t k = 0; k < count; ++k) db->maxLen = std::max(db->maxLen, offsets[(size_t)k + 1] - offsets[(size_t)k]);
+    const size_t wantRes = (size_t)db->total + 64, wantOff = (size_t)(count + 1) * sizeof(int64_t);
+    HIP_TRY(hipMalloc(&db->d_residues, wantRes));
+    db->residueCap = wantRes;
+    HIP_TRY(hipMalloc(&db->d_offsets, wantOff));
+    db->offsetsCap = wantOff;
+    RC_TRY(uploadOnce(db->device, db->d_offsets, offsets.data(), wantOff));
+    if (count > 0) {
+        // the residues never leave the device: gathered from the parent's resident copy
+        int64_t* d_src = nullptr;
+        HIP_TRY(hipMalloc(&d_src, (size_t)count * sizeof(int64_t)));
+        int rc = uploadOnce(db->device, d_src, srcStart.data(), (size_t)count * sizeof(int64_t));
+        hipError_t e = hipSuccess;
+        if (rc == 0) {
+            e = launchGatherSequences(parent->d_residues, d_src, db->d_offsets, count, db->d_residues, nullptr);
+            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        }
+        (void)hipFree(d_src);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(MIOPAL_ERR_HIP, "gathering the subset failed: %s", hipGetErrorString(e));
+    }
+    db->offsets = std::move(offsets);
+    *out = db.release();
+    return 0;
     });
 }
 

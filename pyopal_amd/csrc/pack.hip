@@ -160,6 +160,17 @@ __global__ void decode_global_keys_kernel(const unsigned long long* keys, const 
     if (endJ) endJ[k] = key == 0 ? -1 : onLastRow ? index : lens[k] - 1;
 }
 
+// subset of a resident database (miopalDbCreateSubset): sequence k of the new linear database is the
+// parent's residues [srcStart[k], srcStart[k] + length), one wavefront per sequence
+__global__ __launch_bounds__(256) void gather_sequences_kernel(const uint8_t* src, const int64_t* srcStart,
+                                                               const int64_t* dstOff, int64_t n, uint8_t* dst) {
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t from = srcStart[k], to = dstOff[k], len = dstOff[k + 1] - to;
+    for (int64_t p = lane; p < len; p += 64) dst[to + p] = src[from + p];
+}
+
 __global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = value;
@@ -196,6 +207,14 @@ hipError_t launchDecodeGlobalKeys(const unsigned long long* keys, const int32_t*
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(decode_global_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, keys, lens, n, queryLength,
                        score, endI, endJ);
+    return hipGetLastError();
+}
+
+hipError_t launchGatherSequences(const uint8_t* src, const int64_t* srcStart, const int64_t* dstOff, int64_t n,
+                                 uint8_t* dst, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if ((n + 3) / 4 > INT32_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gather_sequences_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, src, srcStart, dstOff, n, dst);
     return hipGetLastError();
 }
 

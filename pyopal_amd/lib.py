@@ -12,6 +12,7 @@ from __future__ import annotations
 import array
 import threading
 import typing
+import weakref
 
 import numpy as np
 
@@ -249,6 +250,10 @@ class BaseDatabase:
             entry = self._mirrors.get(key)
             if entry is not None:
                 return entry[1]
+            derived = self._mirror_from_parent(device) if shard is None else None
+            if derived is not None:
+                self._mirrors[key] = (self._version, derived)
+                return derived
             seqs = self._get_encoded()
             lo, hi = (0, len(seqs)) if shard is None else shard
             if not 0 <= lo <= hi <= len(seqs):
@@ -262,6 +267,25 @@ class BaseDatabase:
             mirror = _capi.DeviceDatabase(residues, offsets, self.alphabet.length, device)
             self._mirrors[key] = (self._version, mirror)
             return mirror
+
+    def _mirror_from_parent(self, device: int):
+        """A subset made by `Database.mask` / `Database.extract` whose parent is still resident on
+        ``device`` and unchanged gathers its residues there from the parent's mirror instead of
+        uploading them again (the reference's subsets share the parent's
+        sequence buffers, ``src/pyopal/lib.pyx:694-778``). None: build the mirror the ordinary way."""
+        link = getattr(self, "_parent_link", None)
+        if link is None:
+            return None
+        parent_ref, parent_version, my_version, indices = link
+        parent = parent_ref()
+        if parent is None or my_version != self._version:
+            self._parent_link = None     # the parent is gone, or this subset was edited: nothing to share
+            return None
+        with parent._mirror_guard:
+            entry = parent._mirrors.get((device, None))
+            if entry is None or entry[0] != parent_version or parent._version != parent_version:
+                return None
+            return entry[1].subset(indices)
 
     def _invalidate(self) -> None:
         """Called with the write lock held by every mutator."""
@@ -438,8 +462,21 @@ class Database(BaseDatabase):
         subdb._lengths = []
         return subdb
 
+    def _link_subset(self, subdb: "Database", picked: typing.List[int]) -> None:
+        """(read lock held) Remember where the subset came from: while this database and the subset
+        stay as they are, the subset's device mirror is gathered from this one's on the device."""
+        picked = np.asarray(picked, dtype=np.int64)
+        link = getattr(self, "_parent_link", None)
+        if link is not None and link[2] == self._version and link[0]() is not None:
+            # a subset of an (unedited) subset: linked to the database at the root, which is the one
+            # likely to be resident
+            subdb._parent_link = (link[0], link[1], subdb._version, link[3][picked])
+        else:
+            subdb._parent_link = (weakref.ref(self), self._version, subdb._version, picked)
+
     def mask(self, bitmask) -> "Database":
         subdb = self._subset()
+        picked = []
         with self.lock.read:
             size = self._get_size()
             i = 0
@@ -449,13 +486,16 @@ class Database(BaseDatabase):
                 if b:
                     subdb._sequences.append(self._sequences[i])
                     subdb._lengths.append(self._lengths[i])
+                    picked.append(i)
                 i += 1
             if i < size:
                 raise IndexError(bitmask)
+            self._link_subset(subdb, picked)
         return subdb
 
     def extract(self, indices) -> "Database":
         subdb = self._subset()
+        picked = []
         with self.lock.read:
             size = self._get_size()
             for index in indices:
@@ -463,6 +503,8 @@ class Database(BaseDatabase):
                     raise IndexError(index)
                 subdb._sequences.append(self._sequences[index])
                 subdb._lengths.append(self._lengths[index])
+                picked.append(index)
+            self._link_subset(subdb, picked)
         return subdb
 
 

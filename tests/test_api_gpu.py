@@ -145,3 +145,46 @@ def test_align_arrays_extension_matches_align(mode):
     assert len(empty) == 0 and list(empty) == []
     with pytest.raises(ValueError):
         aligner.align_arrays(seqs[5], db, mode="nope")
+
+
+def test_subsets_gather_their_mirror_from_the_parent_on_the_device(monkeypatch):
+    # Database.mask / Database.extract / slices (src/pyopal/lib.pyx:694-778 share the parent's buffers):
+    # while the parent is resident and unchanged, the subset's mirror is gathered from the parent's on
+    # the device (miopalDbCreateSubset) - nothing is uploaded again; after a mutation of either side the
+    # ordinary upload takes over. Scores, indices and full alignments equal the parent's.
+    from pyopal_amd import _capi
+    rng = np.random.default_rng(8)
+    seqs = ["".join(_data.AA20[i] for i in rng.integers(0, 20, size=int(n))) for n in rng.integers(1, 120, size=300)]
+    db = pyopal.Database(seqs)
+    aligner = pyopal.Aligner("BLOSUM62")
+    query = seqs[17]
+    whole = aligner.align(query, db, mode="full", algorithm="sw")
+    uploads, gathers = [], []
+    real_init, real_subset = _capi.DeviceDatabase.__init__, _capi.DeviceDatabase.subset
+    monkeypatch.setattr(_capi.DeviceDatabase, "__init__",
+                        lambda self, *a, **k: (uploads.append(1), real_init(self, *a, **k))[1])
+    monkeypatch.setattr(_capi.DeviceDatabase, "subset",
+                        lambda self, idx: (gathers.append(len(idx)), real_subset(self, idx))[1])
+    picks = [299, 0, 17, 17, 150, 3]
+    mask = [bool(k % 3 == 0) for k in range(300)]
+    for sub, ids in ((db.extract(picks), picks), (db.mask(mask), [k for k in range(300) if mask[k]]),
+                     (db[40:200:7], list(range(40, 200, 7))), (db.extract([]), [])):
+        got = aligner.align(query, sub, mode="full", algorithm="sw")
+        assert [r.target_index for r in got] == list(range(len(ids)))
+        assert [(r.score, r.query_end, r.target_end, r.query_start, r.target_start, r.alignment) for r in got] == \
+               [(whole[k].score, whole[k].query_end, whole[k].target_end, whole[k].query_start, whole[k].target_start,
+                 whole[k].alignment) for k in ids]
+    assert uploads == [] and gathers == [6, 100, 23]     # (an empty subset is never searched on the device)
+    # a subset of a subset chains; an edited subset, or a subset of an edited parent, uploads
+    sub = db.extract(picks)
+    subsub = sub.extract([1, 2])
+    assert [r.score for r in aligner.align(query, subsub)] == [whole[0].score, whole[17].score]
+    assert uploads == [] and gathers[-1] == 2      # gathered from the root's mirror: `sub` itself was never resident
+    sub2 = db.extract(picks)
+    sub2.append(query)
+    assert [r.score for r in aligner.align(query, sub2)] == [whole[k].score for k in picks] + [whole[17].score]
+    assert len(uploads) == 1
+    sub3 = db.extract([1, 2])
+    db.append(query)
+    assert [r.score for r in aligner.align(query, sub3)] == [whole[1].score, whole[2].score]
+    assert len(uploads) == 2
