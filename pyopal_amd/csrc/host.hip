@@ -394,6 +394,8 @@ struct View {
     int64_t* d_boundaryOff = nullptr;
     size_t deviceBytes = 0;
     void* d_meta = nullptr;          // one allocation behind d_ids .. d_boundaryOff (and the pack kernel's prefix)
+    bool packPending = false;        // lists built and uploaded, residues not packed yet (prefetched view)
+    PackArgs pendingPack{};
     size_t packCap = 0, metaCap = 0; // sizes of the two allocations (a refilled handle re-uses them)
     ~View() {
         if (d_pack) (void)hipFree(d_pack);
@@ -423,6 +425,8 @@ struct MiopalDb {
         bool building;                 // placeholder: the view is being built outside the lock
         std::shared_ptr<View> view;
     };
+    // view lists built while the residues were still on their way (opalSearchDatabase: fillHandle)
+    std::shared_ptr<View> prefetched;
     std::mutex viewMutex;
     std::condition_variable viewReady;
     std::list<ViewSlot> views;         // most recent first
@@ -811,8 +815,8 @@ int segmentStride(int overlap) { return std::max(256, (overlap * 3 / 5 + 63) / 6
 
 // Host loops over a million targets (view lists, result structs) are cut into slices worked on by
 // a few threads; MIOPAL_HOST_THREADS overrides the count (default: up to 4).
-int hostThreads(size_t items, size_t perThread) {
-    int t = (int)std::min<size_t>(4, std::max(1u, std::thread::hardware_concurrency()));
+int hostThreads(size_t items, size_t perThread, size_t atMost = 4) {
+    int t = (int)std::min<size_t>(atMost, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* env = getenv("MIOPAL_HOST_THREADS")) t = std::max(1, std::min(64, atoi(env)));
     return (int)std::max<size_t>(1, std::min<size_t>((size_t)t, items / std::max<size_t>(perThread, 1)));
 }
@@ -870,7 +874,28 @@ int viewBlock(MiopalDb* db, size_t bytes, void** out, size_t* cap) {
     return 0;
 }
 
-int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
+int finishView(MiopalDb* db, View* v);
+
+// packNow = false: everything but the pack kernel (which reads the residues on the device): the lists,
+// the device blocks and the upload of the small arrays - what can be done while the residues are still
+// crossing PCIe; finishView() packs.
+int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, bool packNow = true) {
+    if (packNow) {
+        // (lists of this very slice built ahead, beside the upload of the residues: only the packing is left)
+        std::shared_ptr<View> ready;
+        {
+            std::lock_guard<std::mutex> g(db->viewMutex);
+            if (db->prefetched && db->prefetched->start == start && db->prefetched->end == end &&
+                db->prefetched->overlap == overlap)
+                ready = std::move(db->prefetched);
+            db->prefetched.reset();
+        }
+        if (ready) {
+            RC_TRY(finishView(db, ready.get()));
+            *out = ready;
+            return 0;
+        }
+    }
     PhaseTimer pt;
     auto v = std::make_shared<View>();
     v->start = start;
@@ -1038,14 +1063,33 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
         pa.nGroups = v->nGroups;
         pa.padSymbol = db->alphabet;
         pa.pack = v->d_pack;
-        // (the channel's own stream, and a wait for that stream only: other threads' searches go on)
-        HIP_TRY(launchPack(pa, v->totalChunks, up.ch->stream));
-        HIP_TRY(hipStreamSynchronize(up.ch->stream));
-        pt.mark("view: upload + pack");
         v->deviceBytes = packBytes + metaBytes;
+        if (!packNow) {
+            HIP_TRY(hipStreamSynchronize(up.ch->stream));   // (the bounce buffer goes back to the pool)
+            v->pendingPack = pa;
+            v->packPending = true;
+            pt.mark("view: upload (pack later)");
+        } else {
+            // (the channel's own stream, and a wait for that stream only: other threads' searches go on)
+            HIP_TRY(launchPack(pa, v->totalChunks, up.ch->stream));
+            HIP_TRY(hipStreamSynchronize(up.ch->stream));
+            pt.mark("view: upload + pack");
+        }
     }
     v->ids = std::move(ids);
     *out = v;
+    return 0;
+}
+
+int finishView(MiopalDb* db, View* v) {
+    if (!v->packPending) return 0;
+    PhaseTimer pt;
+    UploadLease up(db);
+    RC_TRY(up.acquire(256));
+    HIP_TRY(launchPack(v->pendingPack, v->totalChunks, up.ch->stream));
+    HIP_TRY(hipStreamSynchronize(up.ch->stream));
+    v->packPending = false;
+    pt.mark("view: pack (lists built beside the upload)");
     return 0;
 }
 
@@ -2228,7 +2272,7 @@ int newHandle(std::unique_ptr<MiopalDb>* out, int device) {
 // (Re)fills a handle nobody else is using: the sequences replace whatever it held; device
 // allocations that are large enough stay, the blocks of its cached views are kept for the new views.
 int fillHandle(MiopalDb* db, const ResidueSource& src, std::vector<int64_t>&& offsets, int64_t count,
-               int alphabetLength) {
+               int alphabetLength, bool prefetchView = false) {
     const int device = db->device;
     HIP_TRY(hipSetDevice(device));
     {
@@ -2243,6 +2287,7 @@ int fillHandle(MiopalDb* db, const ResidueSource& src, std::vector<int64_t>&& of
                 }
         }
         db->views.clear();
+        db->prefetched.reset();
     }
     db->alphabet = alphabetLength;
     db->count = count;
@@ -2250,7 +2295,16 @@ int fillHandle(MiopalDb* db, const ResidueSource& src, std::vector<int64_t>&& of
     const std::vector<int64_t>& off = db->offsets;
     db->total = off[(size_t)count];
     db->maxLen = 0;
-    for (int64_t k = 0; k < count; ++k) db->maxLen = std::max(db->maxLen, off[(size_t)k + 1] - off[(size_t)k]);
+    {
+        const int nSlices = hostThreads((size_t)count, 65536);
+        std::vector<int64_t> longest((size_t)nSlices, 0);
+        parallelSlices(nSlices, [&](int t) {
+            int64_t m = 0;
+            for (int64_t k = count * t / nSlices; k < count * (t + 1) / nSlices; ++k) m = std::max(m, off[(size_t)k + 1] - off[(size_t)k]);
+            longest[(size_t)t] = m;
+        });
+        for (int64_t m : longest) db->maxLen = std::max(db->maxLen, m);
+    }
     const size_t wantRes = (size_t)db->total + 64, wantOff = (size_t)(count + 1) * sizeof(int64_t);
     if (db->residueCap < wantRes || db->residueCap / 4 > wantRes + (1u << 20)) {
         if (db->d_residues) HIP_TRY(hipFree(db->d_residues));
@@ -2266,6 +2320,35 @@ int fillHandle(MiopalDb* db, const ResidueSource& src, std::vector<int64_t>&& of
         HIP_TRY(hipMalloc(&db->d_offsets, wantOff));
         db->offsetsCap = wantOff;
     }
+    // opalSearchDatabase hands the whole database over on every call and searches all of it at once: the
+    // lists of that search's packed view only need the lengths, so they are built (and their small arrays
+    // uploaded) by another thread WHILE the residues cross PCIe; the search then only packs. Only for
+    // databases whose targets are shorter than any window of a segmented view (the search would ask for
+    // another view otherwise). A failure here is no error: the search builds its view itself.
+    std::thread viewThread;
+    if (prefetchView && count >= 65536 && db->maxLen <= 256 + 128 && !getenv("MIOPAL_NO_VIEW_PREFETCH")) {
+        try {
+            viewThread = std::thread([db, count, device] {
+                if (hipSetDevice(device) != hipSuccess) return;
+                std::shared_ptr<View> v;
+                try {
+                    if (buildView(db, 0, count, 0, &v, false) != 0) {
+                        (void)hipGetLastError();
+                        return;
+                    }
+                } catch (...) {
+                    return;
+                }
+                std::lock_guard<std::mutex> g(db->viewMutex);
+                db->prefetched = std::move(v);
+            });
+        } catch (const std::exception&) {
+        }
+    }
+    struct Joiner {
+        std::thread& t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{viewThread};
     // residues: gathered (or copied) piece by piece into the bounce pieces and checked there
     const unsigned limit = (unsigned)alphabetLength;
     int bad = 0;
@@ -3248,12 +3331,15 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
     const int64_t n = end - start;
     if (n <= 0) return n < 0 ? fail(MIOPAL_ERR_BAD_ARGUMENT, "bad slice") : 0;
     if (!results) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null results");
-    std::vector<int> score((size_t)n), et, eq, st, sq, alen;
+    // (not a vector: a million zeros written first cost as much as the copy that overwrites them)
+    std::unique_ptr<int[]> scoreOwner(new int[(size_t)n]);
+    int* const score = scoreOwner.get();
+    std::vector<int> et, eq, st, sq, alen;
     std::vector<unsigned char*> aln;
     if (searchType >= OPAL_SEARCH_SCORE_END) { et.resize((size_t)n); eq.resize((size_t)n); }
     if (searchType == OPAL_SEARCH_ALIGNMENT) { st.resize((size_t)n); sq.resize((size_t)n); alen.resize((size_t)n); aln.resize((size_t)n, nullptr); }
     int rc = miopalSearch(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType,
-                          mode, start, end, score.data(), et.empty() ? nullptr : et.data(),
+                          mode, start, end, score, et.empty() ? nullptr : et.data(),
                           eq.empty() ? nullptr : eq.data(), st.empty() ? nullptr : st.data(),
                           sq.empty() ? nullptr : sq.data(), aln.empty() ? nullptr : aln.data(),
                           alen.empty() ? nullptr : alen.data());
@@ -3262,7 +3348,8 @@ int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLengt
         return rc;
     }
     PhaseTimer pt;
-    const int nSlices = hostThreads((size_t)n, 65536);
+    // (a million scattered 40-byte records behind a million pointers: memory latency, more threads help)
+    const int nSlices = hostThreads((size_t)n, 65536, 8);
     parallelSlices(nSlices, [&](int t) {
         for (int64_t k = n * t / nSlices; k < n * (t + 1) / nSlices; ++k) {
             OpalSearchResult* r = results[k];
@@ -3316,11 +3403,35 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
     if (!db || !dbSeqLengths) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to opalSearchDatabase");
     if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
         return fail(MIOPAL_ERR_BAD_ARGUMENT, "alphabet length %d not in 1..32", alphabetLength);
-    std::vector<int64_t> offsets((size_t)dbLength + 1, 0);
-    for (int k = 0; k < dbLength; ++k) {
-        if (dbSeqLengths[k] < 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "negative sequence length");
-        if (dbSeqLengths[k] > 0 && !db[k]) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null sequence %d", k);
-        offsets[(size_t)k + 1] = offsets[(size_t)k] + dbSeqLengths[k];
+    // offsets = prefix sums of the lengths, in slices worked on side by side (a million targets: 12 MB read)
+    std::vector<int64_t> offsets((size_t)dbLength + 1);
+    {
+        const int nSlices = hostThreads((size_t)dbLength, 65536);
+        std::vector<int64_t> sliceSum((size_t)nSlices + 1, 0);
+        std::vector<int> sliceBad((size_t)nSlices, 0);
+        auto lo = [&](int t) { return (int)((int64_t)dbLength * t / nSlices); };
+        parallelSlices(nSlices, [&](int t) {
+            int64_t sum = 0;
+            for (int k = lo(t); k < lo(t + 1); ++k) {
+                if (dbSeqLengths[k] < 0) { sliceBad[(size_t)t] = 1; return; }
+                if (dbSeqLengths[k] > 0 && !db[k]) { sliceBad[(size_t)t] = 2; return; }
+                sum += dbSeqLengths[k];
+            }
+            sliceSum[(size_t)t + 1] = sum;
+        });
+        for (int t = 0; t < nSlices; ++t) {
+            if (sliceBad[(size_t)t] == 1) return fail(MIOPAL_ERR_BAD_ARGUMENT, "negative sequence length");
+            if (sliceBad[(size_t)t] == 2) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null sequence in the database");
+            sliceSum[(size_t)t + 1] += sliceSum[(size_t)t];
+        }
+        parallelSlices(nSlices, [&](int t) {
+            int64_t at = sliceSum[(size_t)t];
+            for (int k = lo(t); k < lo(t + 1); ++k) {
+                offsets[(size_t)k] = at;
+                at += dbSeqLengths[k];
+            }
+        });
+        offsets[(size_t)dbLength] = sliceSum[(size_t)nSlices];
     }
     // a handle of an earlier call, or a new one
     std::unique_ptr<MiopalDb> h;
@@ -3337,7 +3448,7 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
     if (!h) RC_TRY(newHandle(&h, device));
     ResidueSource src;
     src.sequences = (const unsigned char* const*)db;
-    int rc = fillHandle(h.get(), src, std::move(offsets), dbLength, alphabetLength);
+    int rc = fillHandle(h.get(), src, std::move(offsets), dbLength, alphabetLength, /*prefetchView=*/true);
     const auto t1 = std::chrono::steady_clock::now();
     if (rc == 0)
         rc = miopalSearchResults(h.get(), query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
