@@ -188,3 +188,35 @@ def test_subsets_gather_their_mirror_from_the_parent_on_the_device(monkeypatch):
     db.append(query)
     assert [r.score for r in aligner.align(query, sub3)] == [whole[1].score, whole[2].score]
     assert len(uploads) == 2
+
+
+def test_align_over_several_real_devices_equals_one_device():
+    # pyopal_amd.align() in ONE process with several GPUs: one residue-balanced shard of the database per
+    # device, chunks cut at the shard boundaries, absolute target indices, database order with
+    # ordered=True, full alignments - against the answer of device 0 alone. (The per-device launch
+    # attributes of the pair-table kernels - 150 KB of dynamic LDS, hipFuncSetAttribute per device - are
+    # exercised by the 53-residue query.) Skipped on a box with one GPU.
+    from pyopal_amd import _capi
+    if _capi.lib().miopalDeviceCount() < 2:
+        pytest.skip("one GPU visible")
+    rng = np.random.default_rng(12)
+    lengths = np.concatenate([rng.integers(200, 600, size=3000), rng.integers(20, 120, size=9000)])   # skewed
+    seqs = ["".join(_data.AA20[i] for i in rng.integers(0, 20, size=int(n))) for n in lengths]
+    db = pyopal.Database(seqs)
+    query = "".join(_data.AA20[i] for i in rng.integers(0, 20, size=53))
+    long_query = "".join(_data.AA20[i] for i in rng.integers(0, 20, size=200))
+    aligner = pyopal.Aligner("BLOSUM62")
+    for q, mode, algo in ((query, "score", "sw"), (query, "full", "sw"), (long_query, "end", "nw"), (long_query, "score", "sw")):
+        want = aligner.align(q, db, mode=mode, algorithm=algo)      # device 0, whole database
+        for threads in (0, 3):
+            got = list(pyopal.align(q, db, "BLOSUM62", mode=mode, algorithm=algo, threads=threads, ordered=True))
+            assert [r.target_index for r in got] == list(range(len(seqs))), (mode, threads)
+            assert [r.score for r in got] == [r.score for r in want], (mode, algo, threads)
+            if mode != "score":
+                assert [(r.query_end, r.target_end) for r in got] == [(r.query_end, r.target_end) for r in want]
+            if mode == "full":
+                assert [(r.query_start, r.target_start, r.alignment) for r in got] == \
+                       [(r.query_start, r.target_start, r.alignment) for r in want]
+    # every device holds a shard, none the whole database
+    keys = sorted(k for k in db._mirrors if k[1] is not None)
+    assert len(keys) >= 2 and all(hi - lo < len(seqs) for _, (lo, hi) in keys)
