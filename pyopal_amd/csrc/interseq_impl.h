@@ -1112,6 +1112,57 @@ static __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
 // (unsigned arithmetic: the product wraps modulo 2^32 for negative or large v, no signed overflow)
 static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)v * 0x00010001u; }
 
+// Pacing of the wavefronts that share a SIMD (round 3). The twelve wavefronts of a unit sweep groups of
+// (nearly) equal length and meet at the unit's barrier, but a SIMD serves its OLDEST ready wavefront
+// first: of three with equal work the first is done after little more than half the unit's time, the
+// last sweeps the rest of its group alone on a SIMD it cannot fill, and meanwhile the others wait at the
+// barrier (PMC of the round-2 kernel on BASELINE configs[3]: wavefronts parked 47 % of their life,
+// 15 % in the one-strip kernel whose wavefronts fetch new groups on their own). Each wavefront
+// therefore publishes the chunk it is on in LDS, per hardware SIMD, and the one furthest behind runs at
+// a higher priority: the three advance together and reach the barrier together.
+#ifndef MIOPAL_STRIP_PACE
+#define MIOPAL_STRIP_PACE 1
+#endif
+constexpr int kPaceInts = 20;   // 4 SIMDs x 4 slots of progress + 4 slot counters
+struct SimdPace {
+    int* mine = nullptr;        // this wavefront's progress word
+    const int4* simdRow = nullptr;
+    // (once per kernel; `lds` = kPaceInts ints, every thread of the workgroup calls this)
+    __device__ __forceinline__ void init(int* lds, int lane) {
+        if (threadIdx.x < kPaceInts) lds[threadIdx.x] = threadIdx.x < 16 ? INT32_MAX : 0;
+        __syncthreads();
+        // HW_REG_HW_ID (4), SIMD_ID = bits 5:4
+        const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&lds[16 + simd], 1);
+        slot = __builtin_amdgcn_readfirstlane(slot) & 3;
+        mine = lds + simd * 4 + slot;
+        simdRow = reinterpret_cast<const int4*>(lds + simd * 4);
+    }
+    __device__ __forceinline__ void begin(int lane) const {
+        if (MIOPAL_STRIP_PACE && lane == 0) *mine = 0;
+    }
+    __device__ __forceinline__ void end(int lane) const {
+        if (MIOPAL_STRIP_PACE && lane == 0) *mine = INT32_MAX;   // (at the barrier: nobody waits for this one)
+    }
+    // at the top of chunk c; `fixed`: the wavefront keeps the priority it has (a long group)
+    __device__ __forceinline__ void step(int c, int lane, bool fixed) const {
+        if (!MIOPAL_STRIP_PACE || fixed) return;
+        if (lane == 0) *mine = c;
+        const int4 p = *simdRow;
+        const int behind = __builtin_amdgcn_readfirstlane(min(min(p.x, p.y), min(p.z, p.w)));
+        if (c <= behind) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+};
+
+// The same pacing in the one-strip kernels, by what is left of each wavefront's current group: the last
+// groups of a SIMD end together instead of one after the other (round 3; 393k / 500k targets x 300 at
+// Q = 53: 0.634 -> 0.574 / 0.816 -> 0.742 ms, nothing lost at other sizes: profiles/r03_headline_pace_ab.txt)
+#ifndef MIOPAL_HEADLINE_PACE
+#define MIOPAL_HEADLINE_PACE 1
+#endif
+
 template <int R, bool LOC>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kernel(InterseqArgs a) {
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
@@ -1146,6 +1197,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
     int* simdTaken = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);
     if (threadIdx.x < 4) simdTaken[threadIdx.x] = 0;
     __syncthreads();
+    // (the wavefronts of a SIMD paced by what is left of their groups: MIOPAL_HEADLINE_PACE above)
+    SimdPace pace;
+    if (MIOPAL_HEADLINE_PACE) pace.init(simdTaken + 4, lane);
 
     // (wave-uniform by construction; said so, or everything derived from it would sit in VGPRs)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1224,6 +1278,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
         for (int c = 0; c < nChunks; ++c) {
             uint2 nxt = {0, 0};
             if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+            if (MIOPAL_HEADLINE_PACE) pace.step(c - nChunks, lane, nChunks > a.priorityChunks);
             uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
             for (int cc = 0; cc < 4; ++cc) {
@@ -1330,11 +1385,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
             a.overflow[base + kLanes + lane] = hi >= a.biasedLimit;
         }
     }
+    if (MIOPAL_HEADLINE_PACE && lane == 0) *pace.mine = INT32_MAX;   // (done: nobody waits for this one)
 }
 
 template <int R, bool LOC>
 static hipError_t launchPairBiasedR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;  // table + per-SIMD counters
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16 + kPaceInts * sizeof(int);  // table + per-SIMD counters (+ pacing)
     static uint64_t configured = 0;  // one bit per device; setting the attribute twice is harmless
     if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_biased_kernel<R, LOC>),
@@ -1396,50 +1452,6 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 #ifndef MIOPAL_STRIP_SLACK
 #define MIOPAL_STRIP_SLACK 0
 #endif
-// Pacing of the wavefronts that share a SIMD (round 3). The twelve wavefronts of a unit sweep groups of
-// (nearly) equal length and meet at the unit's barrier, but a SIMD serves its OLDEST ready wavefront
-// first: of three with equal work the first is done after little more than half the unit's time, the
-// last sweeps the rest of its group alone on a SIMD it cannot fill, and meanwhile the others wait at the
-// barrier (PMC of the round-2 kernel on BASELINE configs[3]: wavefronts parked 47 % of their life,
-// 15 % in the one-strip kernel whose wavefronts fetch new groups on their own). Each wavefront
-// therefore publishes the chunk it is on in LDS, per hardware SIMD, and the one furthest behind runs at
-// a higher priority: the three advance together and reach the barrier together.
-#ifndef MIOPAL_STRIP_PACE
-#define MIOPAL_STRIP_PACE 1
-#endif
-constexpr int kPaceInts = 20;   // 4 SIMDs x 4 slots of progress + 4 slot counters
-struct SimdPace {
-    int* mine = nullptr;        // this wavefront's progress word
-    const int4* simdRow = nullptr;
-    // (once per kernel; `lds` = kPaceInts ints, every thread of the workgroup calls this)
-    __device__ __forceinline__ void init(int* lds, int lane) {
-        if (threadIdx.x < kPaceInts) lds[threadIdx.x] = threadIdx.x < 16 ? INT32_MAX : 0;
-        __syncthreads();
-        // HW_REG_HW_ID (4), SIMD_ID = bits 5:4
-        const int simd = (int)__builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11)) & 3;
-        int slot = 0;
-        if (lane == 0) slot = atomicAdd(&lds[16 + simd], 1);
-        slot = __builtin_amdgcn_readfirstlane(slot) & 3;
-        mine = lds + simd * 4 + slot;
-        simdRow = reinterpret_cast<const int4*>(lds + simd * 4);
-    }
-    __device__ __forceinline__ void begin(int lane) const {
-        if (MIOPAL_STRIP_PACE && lane == 0) *mine = 0;
-    }
-    __device__ __forceinline__ void end(int lane) const {
-        if (MIOPAL_STRIP_PACE && lane == 0) *mine = INT32_MAX;   // (at the barrier: nobody waits for this one)
-    }
-    // at the top of chunk c; `fixed`: the wavefront keeps the priority it has (a long group)
-    __device__ __forceinline__ void step(int c, int lane, bool fixed) const {
-        if (!MIOPAL_STRIP_PACE || fixed) return;
-        if (lane == 0) *mine = c;
-        const int4 p = *simdRow;
-        const int behind = __builtin_amdgcn_readfirstlane(min(min(p.x, p.y), min(p.z, p.w)));
-        if (c <= behind) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(0);
-    }
-};
-
 constexpr int kStripPoison = 1 << 30;
 constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
 
@@ -1837,6 +1849,8 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
     int* simdTaken = reinterpret_cast<int*>(pairs + nSym * nSym * SLOTS);
     if (threadIdx.x < 4) simdTaken[threadIdx.x] = 0;
     __syncthreads();
+    SimdPace pace;
+    if (MIOPAL_HEADLINE_PACE) pace.init(simdTaken + 4, lane);
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     constexpr int kTier12[4][3] = {{0, 6, 11}, {1, 7, 8}, {2, 5, 9}, {3, 4, 10}};
@@ -1910,6 +1924,7 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
         for (int c = 0; c < nChunks; ++c) {
             uint2 nxt = {0, 0};
             if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
+            if (MIOPAL_HEADLINE_PACE) pace.step(c - nChunks, lane, nChunks > a.priorityChunks);
             uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
             for (int cc = 0; cc < 4; ++cc) {
@@ -2039,11 +2054,12 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
             a.overflow[base + kLanes + lane] = 0;
         }
     }
+    if (MIOPAL_HEADLINE_PACE && lane == 0) *pace.mine = INT32_MAX;   // (done: nobody waits for this one)
 }
 
 template <int R>
 static hipError_t launchPairGlobalR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16;
+    const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16 + kPaceInts * sizeof(int);
     static uint64_t configured = 0;
     if (firstUseOnThisDevice(&configured)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_global_kernel<R>),
