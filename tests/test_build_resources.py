@@ -39,7 +39,26 @@ def test_hot_kernels_do_not_spill():
     for name in list(bad):
         if "interseq_kernel" in name and not bad[name].get("VGPRs Spill", 0) and bad[name]["ScratchSize [bytes/lane]"] <= 64:
             del bad[name]
+    # The strips kernels (units of (batch, strip) taken in a loop around the sweep) park a few per-unit
+    # values - boundary-row pointers, lane offsets - in scratch around the sweep at their tallest strips:
+    # a handful of instructions per UNIT, allowed up to a bound; that none of them sits inside a column
+    # loop is checked on the code itself by test_spills_of_the_strips_kernels_stay_out_of_the_column_loops.
+    for name in list(bad):
+        if "strips_kernel" in name and bad[name].get("VGPRs Spill", 0) <= 24 and bad[name]["ScratchSize [bytes/lane]"] <= 128:
+            del bad[name]
     assert not bad, bad
+
+
+def test_spills_of_the_strips_kernels_stay_out_of_the_column_loops():
+    # recompiles the two translation units with the tallest strips (hipcc cross-compiles: no GPU) and reads
+    # the assembly: a basic block that holds a column of cells must not touch scratch memory
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(CSRC), "..", "tools", "check_hot_loops.py")
+    out = subprocess.run([sys.executable, tool, "interseq_glbs16_b", "interseq_swbs16_b"], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("column blocks") >= 6, out.stdout
 
 
 def test_pair_table_kernels_keep_three_wavefronts_per_simd():
