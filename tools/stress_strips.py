@@ -21,20 +21,30 @@ cases = [
     ("log-normal 500k, Q=150", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER, "score"),
     ("log-normal 500k, Q=150, end locations", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER, "end"),
     ("30k x 300, Q=640 (few batches, 13 strips)", np.full(30_000, 300), 640, ITER, "score"),
+    # round 3: NW / HW / OV of several strips (interseq_pair_global_strips_kernel) against the general kernel
+    ("100k x 2000, Q=2000, nw", np.full(100_000, 2000), 2000, max(1, ITER // 4), "score", "nw"),
+    ("100k x 2000, Q=2000, ov end locations", np.full(100_000, 2000), 2000, max(1, ITER // 4), "end", "ov"),
+    ("1M x 300, Q=300, hw", np.full(1_000_000, 300), 300, ITER, "score", "hw"),
+    ("1M x 300, Q=150, nw end locations", np.full(1_000_000, 300), 150, ITER, "end", "nw"),
+    ("log-normal 500k, Q=150, ov", np.clip(rng.lognormal(5.5, 0.6, size=500_000).astype(int), 1, 6000), 150, ITER, "score", "ov"),
+    ("30k x 300, Q=640, hw (few batches, 13 strips)", np.full(30_000, 300), 640, ITER, "score", "hw"),
 ]
-for name, lengths, Q, iters, mode in cases:
+for case in cases:
+    name, lengths, Q, iters, mode = case[:5]
+    algo = case[5] if len(case) > 5 else "sw"
+    off_switch = "MIOPAL_NO_PAIR_STRIPS" if algo == "sw" else "MIOPAL_NO_GLOBAL_STRIPS"
     res, off = _data.random_db(rng, lengths)
     q = _data.random_protein(rng, Q)
     db = _capi.DeviceDatabase(res, off, 24)
-    os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
-    want = db.search(q, m, 3, 1, mode, "sw")
+    os.environ[off_switch] = "1"
+    want = db.search(q, m, 3, 1, mode, algo)
     assert (_capi.DeviceDatabase.last_routing()[1] & 15) == 1
-    os.environ.pop("MIOPAL_NO_PAIR_STRIPS")
+    os.environ.pop(off_switch)
     bad = 0
     t0 = time.perf_counter()
     for k in range(iters):
-        got = db.search(q, m, 3, 1, mode, "sw")
-        assert _capi.DeviceDatabase.last_routing()[1] == 6
+        got = db.search(q, m, 3, 1, mode, algo)
+        assert _capi.DeviceDatabase.last_routing()[1] == (6 if algo == "sw" else 7)
         if not all(np.array_equal(got[key], want[key]) for key in want):
             bad += 1
             print(f"  {name}: run {k}: {sum(int((got[key] != want[key]).sum()) for key in want)} values differ", flush=True)
