@@ -1452,6 +1452,12 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 #ifndef MIOPAL_STRIP_SLACK
 #define MIOPAL_STRIP_SLACK 0
 #endif
+// progress is published every (mask + 1) chunks and at the end of the sweep (round 3: every 8 chunks
+// instead of 4, and the counter fetched a chunk before it is needed, change nothing measurable - the
+// hand-over is not what the wavefronts wait for: profiles/r03_handover_experiments.txt)
+#ifndef MIOPAL_STRIP_PUBLISH_MASK
+#define MIOPAL_STRIP_PUBLISH_MASK 3
+#endif
 constexpr int kStripPoison = 1 << 30;
 constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
 
@@ -1608,7 +1614,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 uint2 nxt = {0, 0};
                 if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
                 pace.step(c, lane, longGroup);
-                if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
+                if constexpr (kFromAbove) {
+                    waitFor(min(c + kLag, nChunks));
+                    // (a unit that has given up computes nothing more: what it would publish from rows that
+                    // never arrived could be taken for real by a strip below that needs no further poll)
+                    if (dead) break;
+                }
                 uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
                 for (int cc = 0; cc < 4; ++cc) {
@@ -1697,7 +1708,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                     shift = 0;
                 }
                 // (every fourth chunk and the last: the wait below also waits for the loads in flight)
-                if (kToBelow && (((c + 1) & 3) == 0 || c + 1 == nChunks)) {
+                if (kToBelow && (((c + 1) & MIOPAL_STRIP_PUBLISH_MASK) == 0 || c + 1 == nChunks)) {
                     // every row store of the chunks has COMPLETED before the counter moves (stripPublish, common.h)
                     stripPublish(progOut, c + 1, lane);
                 }
@@ -2279,7 +2290,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                 uint2 nxt = {0, 0};
                 if (c + 1 < nChunks) nxt = pack[(size_t)(c + 1) * kLanes + lane];
                 pace.step(c, lane, longGroup);
-                if constexpr (kFromAbove) waitFor(min(c + kLag, nChunks));
+                if constexpr (kFromAbove) {
+                    waitFor(min(c + kLag, nChunks));
+                    // (a unit that has given up computes nothing more: what it would publish from rows that
+                    // never arrived could be taken for real by a strip below that needs no further poll)
+                    if (dead) break;
+                }
                 uint32_t ra = cur.x, rb = cur.y;
 #pragma unroll 1
                 for (int cc = 0; cc < 4; ++cc) {
@@ -2434,7 +2450,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     sigma -= shift;
                     shift = 0;
                 }
-                if (kToBelow && (((c + 1) & 3) == 0 || c + 1 == nChunks)) stripPublish(progOut, c + 1, lane);
+                if (kToBelow && (((c + 1) & MIOPAL_STRIP_PUBLISH_MASK) == 0 || c + 1 == nChunks)) stripPublish(progOut, c + 1, lane);
             }
         };
         if (!dead) {
