@@ -56,6 +56,7 @@ struct InterseqArgs {
     int stripAbortAt;          //   the view is redone by the next rung anyway (it adds the same to *stripGaveUp)
     int* stripGaveUp;          //   = the overflow counter the host reads after the scatter
     int batchGroups;           // strips kernel: groups a workgroup sweeps side by side (1..12; fewer when the groups are few)
+    const int32_t* known;      // strips kernel, second pass of an `end` search: every lane half's optimum (view order)
     // one-strip biased Smith-Waterman kernel, scores only: results straight into database order (no view-order
     // array, no scatter kernel); directOut may be pinned host memory (miopalSearch: no D2H copy either)
     int32_t* directOut;        // already offset by - sliceStart: entry directIds[view position]; null: a.score
@@ -203,6 +204,7 @@ enum PairFlavour : int {
 };
 // limits of the biased flavour (host-side range checks; the kernel's constants are in interseq_impl.h)
 constexpr int kPairStripsMaxRows = 52, kPairStripsMaxRowsLoc = 48;   // tallest strips of the multi-strip pair-table kernel
+constexpr int kPairStripsMaxRowsKnown = 40;   // ... of an `end` search in two sweeps (scores, then the cell that holds them)
 constexpr int kBiasedScoreLimit = 25600;   // = kBiasedLimit: a best at or above it is recomputed
 constexpr int kBiasedMaxMagnitude = 1024;  // |score|, open - ext, ext - open
 constexpr int kBiasedMaxExt = 512;
@@ -223,6 +225,8 @@ hipError_t launchInterseqPairSwStripsA(const InterseqArgs& a, int rows, int comp
 hipError_t launchInterseqPairSwStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairSwStripsLocB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
+// second pass of an `end` search: the first cell that holds each target's known optimum (a.known)
+hipError_t launchInterseqPairSwStripsKnownA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalStripsA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalStripsB(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);
 hipError_t launchInterseqPairGlobalStripsLocA(const InterseqArgs& a, int rows, int computeUnits, hipStream_t stream);

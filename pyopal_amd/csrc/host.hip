@@ -116,7 +116,7 @@ inline hipError_t createUploadStream(hipStream_t* s) {
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
 constexpr int64_t kDirBudget = 2ll << 30;  // direction workspace: 2 x this per device-resident traceback batch, 1 x per host-built batch
 constexpr int64_t kInt32Safe = 1ll << 29;
-constexpr int kMaxDirectRecompute = 2048;  // saturated half-float lanes sent straight to int32
+constexpr int kMaxDirectRecompute = 2048;  // lanes that left their range and are sent straight to int32: at least this many (see directLimit)
 // A lane that owns a whole target walks its columns one after the other (about 0.8 us per
 // column of 56 rows): whatever the number of targets, the lane-per-target kernels need
 // (longest target) x that. Few targets of a one-strip query are done sooner by the
@@ -1202,6 +1202,9 @@ struct Search {
     int* d_stripError = nullptr;      // units of intraseq_strips_kernel that gave up waiting (never seen)
     int stripErrorHost = 0;
     bool stripsEndsDeclined = false;  // ... with end locations: a probe of the longest groups left its range of 384
+    // Smith-Waterman end locations of several strips whose scores are beyond the row keys' range: two sweeps of
+    // the strips kernel - scores, then the first cell that holds each target's score (round 3)
+    bool twoPassEnds = false;
     // miopalSearch: a pinned, device-visible buffer the scores may be written to directly (the one-strip
     // Smith-Waterman fast path scatters into it from the kernel); wroteHost says that it was used
     int32_t* hostScoreOut = nullptr;
@@ -1536,17 +1539,21 @@ struct Search {
             const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
             // (with end locations every value is scaled by 2^bits: the row inside a strip of 32 .. 48 rows)
             const bool wantEnds = searchType != OPAL_SEARCH_SCORE;
+            // (two sweeps: unscaled values like a score search, strips of at most 40 rows; MIOPAL_TWO_PASS_ENDS=1
+            // asks for them whatever the scores - tests)
+            if (wantEnds && mode == OPAL_MODE_SW && getenv("MIOPAL_TWO_PASS_ENDS")) twoPassEnds = true;
+            const bool rowKeyEnds = wantEnds && !twoPassEnds;
             auto band = [&](int rowsP) {
-                const int sbits = wantEnds ? locRowBitsHost(rowsP) : 0;
-                return (up << sbits) <= kBiasedMaxStepUp && (down << sbits) <= (wantEnds ? kLocGuardBand : kBiasedMaxMagnitude) &&
+                const int sbits = rowKeyEnds ? locRowBitsHost(rowsP) : 0;
+                return (up << sbits) <= kBiasedMaxStepUp && (down << sbits) <= (rowKeyEnds ? kLocGuardBand : kBiasedMaxMagnitude) &&
                        5 * ((int64_t)ext << sbits) <= kLocMaxShift && minScore > kBiasedPad;
             };
             const int single = std::max(2, (Q + 1) / 2 * 2);
             const bool oneStrip = Q <= kLanes && interseqPairFits(single, A + 1);
-            int maxRows = wantEnds ? kPairStripsMaxRowsLoc : kPairStripsMaxRows;
+            int maxRows = !wantEnds ? kPairStripsMaxRows : twoPassEnds ? kPairStripsMaxRowsKnown : kPairStripsMaxRowsLoc;
             while (maxRows >= 32 && !interseqPairFits(maxRows, A + 1)) maxRows -= 2;
             if (mode == OPAL_MODE_SW && Q < (1 << 20) && useHalf && !oneStrip && maxRows >= 32 &&
-                !pairStripsRefused && !(wantEnds && stripsEndsDeclined) && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
+                !pairStripsRefused && !(wantEnds && stripsEndsDeclined && !twoPassEnds) && !(noPair && noPair[0] == '1') && !getenv("MIOPAL_NO_BIASED") &&
                 !getenv("MIOPAL_NO_PAIR_STRIPS") && !getenv("MIOPAL_STRIPS")) {
                 const int ns = std::max(2, (Q + maxRows - 1) / maxRows);
                 const int rowsP = ((Q + ns - 1) / ns + 1) / 2 * 2;
@@ -1734,7 +1741,10 @@ struct Search {
             // the NaN patterns, a step down (score + ext, open - ext) within the room below zero.
             // With end locations every value is scaled by 2^bits (row keys in the low bits).
             const int pairRows = std::max(2, (Q + 1) / 2 * 2);
-            const int bits = locate ? locRowBitsHost(pairStrips ? stripRows : pairRows) : 0;
+            // (row keys in the low bits of every value - unless the end locations come from a second sweep)
+            const bool twoPass = pairStrips && sw && locate && twoPassEnds;
+            const bool rowKeys = locate && !twoPass;
+            const int bits = rowKeys ? locRowBitsHost(pairStrips ? stripRows : pairRows) : 0;
             const int64_t up = std::max<int64_t>((int64_t)maxScore + ext, (int64_t)ext - open);
             const int64_t down = std::max<int64_t>(-((int64_t)minScore + ext), (int64_t)open - ext);
             // (A step up of more than 0x0400 could carry a finite half past the NaN patterns, 0x7C00 to
@@ -1742,10 +1752,10 @@ struct Search {
             // by the excess, so that the cell it would jump from is itself flagged.)
             const bool biasedFits = nStrips == 1 && useHalf && !getenv("MIOPAL_NO_BIASED") &&
                                     (up << bits) <= kBiasedMaxStepUp &&
-                                    (down << bits) <= (locate ? kLocGuardBand : kBiasedMaxMagnitude) &&
+                                    (down << bits) <= (rowKeys ? kLocGuardBand : kBiasedMaxMagnitude) &&
                                     5 * ((int64_t)ext << bits) <= kLocMaxShift && minScore > kBiasedPad;
             const int biasedLimit =
-                (int)(((locate ? 0x7C00 - kLocZeroPattern - kLocMaxShift : kBiasedScoreLimit) -
+                (int)(((rowKeys ? 0x7C00 - kLocZeroPattern - kLocMaxShift : kBiasedScoreLimit) -
                        std::max<int64_t>(0, (up << bits) - 0x0400)) >> bits);
             const bool usePair = sw && nStrips == 1 && !(noPair && noPair[0] == '1') &&
                                  interseqPairFits(biasedFits ? pairRows : rows, nSym) && (!locate || biasedFits);
@@ -1938,6 +1948,12 @@ struct Search {
             // (the strips kernels: always - the count also brings back the lanes of a unit that gave up on
             // the strip above it; searches of several strips take milliseconds, the 4-byte download is free)
             const bool mayOverflow = sw ? (reach >= limit || pairStrips) : globalStrips;
+            // How many flagged lanes are redone one by one before the whole view takes the next rung: the int32
+            // kernel fills about 1e12 cells a second, the next rung 5e12 .. 8e12 over the WHOLE view - an eighth
+            // of the view's targets costs the same either way (round 3; it was 2048 whatever the size: 0.3 % of
+            // 1M x 300 beyond the row keys' 384 at Q = 1000 sent the other 99.7 % through a second launch)
+            const int64_t directLimit = getenv("MIOPAL_FIXED_DIRECT_LIMIT") ? kMaxDirectRecompute
+                                        : std::max<int64_t>(kMaxDirectRecompute, (view->nPacked - packedSkip) / 8);
             if (mayOverflow) HIP_TRY(hipMemsetAsync(ct, 0, sizeof(int32_t), stream));
             InterseqArgs ia{};
             ia.pack = view->d_pack;
@@ -2001,7 +2017,7 @@ struct Search {
                 if (mayOverflow && sw) {
                     // more flagged lanes than are redone one by one: the launch stops, the view takes the next rung
                     ia.stripAbort = (int*)us + ints - 1;
-                    ia.stripAbortAt = 2 * kMaxDirectRecompute;
+                    ia.stripAbortAt = (int)std::min<int64_t>(2 * directLimit, INT32_MAX / 2);
                     ia.stripGaveUp = (int*)ct;
                 }
                 // (the scores-only form of the NW / HW / OV kernel folds OV's candidates into the view scores,
@@ -2054,7 +2070,7 @@ struct Search {
                 hipError_t pe = hipSuccess;
                 // (random pairs only get there in the linear regime of the scoring system, and then score
                 // about half a unit per aligned residue: nothing to probe for under ~500 residues)
-                if (sw && locate && mayOverflow && std::min(Q, view->maxPackedLen) >= 512 && !getenv("MIOPAL_PAIR_STRIPS")) {
+                if (sw && rowKeys && mayOverflow && std::min(Q, view->maxPackedLen) >= 512 && !getenv("MIOPAL_PAIR_STRIPS")) {
                     // With end locations a lane is exact below 384 (768 for strips of 32 rows). Scores of
                     // long queries against long targets under cheap gaps are in the thousands - every lane
                     // would be redone, and a launch that gives up half-way has cost half its time. The
@@ -2076,7 +2092,10 @@ struct Search {
                         int beyond = 0;
                         for (int32_t v : seen) beyond += v >= biasedLimit;
                         if (2 * beyond >= lanes) {
+                            // (round 3: two sweeps of this kernel instead of the general kernel's row scans;
+                            // MIOPAL_NO_TWO_PASS_ENDS restores round 2)
                             stripsEndsDeclined = true;
+                            twoPassEnds = !getenv("MIOPAL_NO_TWO_PASS_ENDS");
                             return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
                         }
                         // (the probe's units and scores are wiped: the real launch starts from zero)
@@ -2084,8 +2103,18 @@ struct Search {
                         HIP_TRY(hipMemsetAsync(ia.score, 0, (size_t)view->nGroups * kGroupTargets * sizeof(int32_t), stream));
                     }
                 }
-                if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, stripsFlavour, pairUnits, stream, locate);
+                if (pe == hipSuccess) pe = launchInterseqPair(ia, rows, stripsFlavour, pairUnits, stream, rowKeys);
                 if (pe == hipSuccess && sidePending) RC_TRY(enqueueSide());
+                if (pe == hipSuccess && twoPass) {
+                    // second sweep: the first cell (column-major) that holds each target's score, as keys
+                    InterseqArgs second = ia;
+                    second.known = ia.score;
+                    second.overflow = nullptr;
+                    second.stripAbort = nullptr;
+                    second.faultUnit1 = 0;
+                    HIP_TRY(hipMemsetAsync(ia.unitCounter, 0, ((size_t)ia.nGroups * nStrips + 1) * sizeof(int), stream));
+                    pe = launchInterseqPair(second, rows, stripsFlavour, pairUnits, stream, false);
+                }
                 if (pe != hipSuccess) {
                     // (e.g. the runtime refuses 150 KB of dynamic LDS: start over on the general kernel)
                     (void)hipGetLastError();
@@ -2208,7 +2237,13 @@ struct Search {
                 int32_t count = 0;
                 RC_TRY(ws->stageDownload(&count, ct, sizeof(int32_t)));
                 RC_TRY(ws->finishDownloads());
-                if ((halfFloat || biased || swShifted || pairStrips) && count > kMaxDirectRecompute) {
+                if (pairStrips && sw && rowKeys && count > directLimit && !twoPassEnds && !getenv("MIOPAL_NO_TWO_PASS_ENDS")) {
+                    // many lanes left the row keys' range (384 .. 768): the scores' own range is 25600 -
+                    // two sweeps of the strips kernel before the int16 rung
+                    twoPassEnds = true;
+                    return scorePassImpl(d_score, d_endI, d_endJ, useHalf);
+                }
+                if ((halfFloat || biased || swShifted || pairStrips) && count > directLimit) {
                     // many targets left the half-float range: second rung, int16 lanes,
                     // over the whole view (its results overwrite the first pass)
                     return scorePassImpl(d_score, d_endI, d_endJ, false);

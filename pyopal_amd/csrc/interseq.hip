@@ -65,6 +65,11 @@ hipError_t launchInterseqPair(const InterseqArgs& a, int rowsPerStrip, PairFlavo
         case kPairSwStrips:
             if (rowsPerStrip < 32 || rowsPerStrip > (locate ? kPairStripsMaxRowsLoc : kPairStripsMaxRows) || (rowsPerStrip & 1))
                 return hipErrorInvalidValue;
+            if (a.known) {
+                // (second pass of an `end` search: the known optimum is looked for, no row keys)
+                if (locate || rowsPerStrip > kPairStripsMaxRowsKnown) return hipErrorInvalidValue;
+                return launchInterseqPairSwStripsKnownA(a, rowsPerStrip, computeUnits, stream);
+            }
             if (locate) {
                 if (rowsPerStrip < 48) return launchInterseqPairSwStripsLocA(a, rowsPerStrip, computeUnits, stream);
                 return launchInterseqPairSwStripsLocB(a, rowsPerStrip, computeUnits, stream);

@@ -1461,8 +1461,14 @@ static hipError_t launchPairBiased(const InterseqArgs& a, int rowsPerStrip, int 
 constexpr int kStripPoison = 1 << 30;
 constexpr int kStripSpinCap = 1 << 21;    // x s_sleep 8 (512 cycles): about half a second
 
-template <int R, bool LOC>
+// KNOWN (round 3, second pass of an `end` search whose scores are beyond the row keys' range): the optimum
+// of every lane half is known (a.known, view order, from the scores-only pass of this very kernel); the
+// sweep is the same, but instead of a running maximum every column's maximum is compared with the optimum,
+// and the first time they are equal - once per lane half and strip at most - a scan of the column's rows
+// finds the first row that holds it. The (score, column, row) keys are the ones of LOC.
+template <int R, bool LOC, bool KNOWN = false>
 __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kernel(InterseqArgs a) {
+    static_assert(!(LOC && KNOWN), "row keys or a known optimum");
     constexpr int SLOTS = PairLayout<R>::kRowSlots;
     constexpr int NB4 = (R + 3) / 4;
     // end locations (LOC): values scaled by 2^kBits, the row inside the strip in the low bits of what
@@ -1575,6 +1581,17 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
 
         uint32_t best = 0u;                 // true values (LOC: keys), integer order
         int colA = -1, colB = -1;           // LOC: column of the first maximum of each half in this strip
+        // KNOWN: the optimum of both halves as one packed value; a half without a positive optimum, or whose
+        // optimum is beyond the exact range (redone by the next rung), has nothing to find
+        uint32_t target2 = 0u;
+        bool foundA = true, foundB = true;
+        if constexpr (KNOWN) {
+            const size_t kbase = (size_t)g * kGroupTargets;
+            const int kA = a.known[kbase + lane], kB = a.known[kbase + kLanes + lane];
+            foundA = kA <= 0 || kA >= a.biasedLimit;
+            foundB = kB <= 0 || kB >= a.biasedLimit;
+            target2 = ((uint32_t)(foundB ? 0xffff : kB) << 16) | (uint32_t)(foundA ? 0xffff : kA);
+        }
         // the sweep, compiled for the three kinds of strip (first / inner / last): no selects between
         // border and row above, no stores from the last strip
         auto sweep = [&](auto fromAboveC, auto toBelowC) {
@@ -1604,7 +1621,9 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
                                                       __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
             };
-            constexpr int kWant = R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
+            // (the second pass of an `end` search has a row scan inside the column loop: it gives the
+            // registers of two prefetched blocks of pair-table rows for it)
+            constexpr int kWant = KNOWN ? 1 : R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
             constexpr int kAhead = NB4 > kWant ? kWant : 1;
             const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
             uint4 vn[kAhead];
@@ -1681,6 +1700,30 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                             best = (best & 0xffffu) | (cand & 0xffff0000u);
                             colB = j;
                         }
+                    } else if constexpr (KNOWN) {
+                        const uint32_t x = (cm - fl) ^ target2;
+                        const bool hitA = !foundA && (x & 0xffffu) == 0, hitB = !foundB && (x >> 16) == 0;
+                        if (__builtin_amdgcn_ballot_w64(hitA || hitB) != 0) {
+                            // the first row of this column that holds the optimum of its half
+                            int ia = 0, ib = 0;
+#pragma unroll
+                            for (int r = R - 1; r >= 0; --r) {
+                                const uint32_t d = (H[r] - fl) ^ target2;
+                                if ((d & 0xffffu) == 0) ia = r;
+                                if ((d >> 16) == 0) ib = r;
+                                asm volatile("" : "+v"(ia), "+v"(ib));
+                            }
+                            // (only remembered here: the keys leave after the sweep, when the DP state is dead -
+                            // anything more inside the column loop costs registers the loop does not have)
+                            if (hitA) {
+                                colA = (j << 6) | ia;
+                                foundA = true;
+                            }
+                            if (hitB) {
+                                colB = (j << 6) | ib;
+                                foundB = true;
+                            }
+                        }
                     } else {
                         best = pk_max_u16(best, cm - fl);
                     }
@@ -1728,6 +1771,17 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             if (a.overflow) a.overflow[base + lane] = a.overflow[base + kLanes + lane] = 1;
             continue;
         }
+        if constexpr (KNOWN) {
+            // (score, column, row) of the first cell of this strip that holds the optimum; scores and flags are
+            // the first pass's
+            auto key = [&](uint32_t score, int where) -> unsigned long long {
+                return ((unsigned long long)score << 40) | ((unsigned long long)(0xFFFFFu - (unsigned)(where >> 6)) << 20) |
+                       (unsigned long long)(0xFFFFFu - (unsigned)(s * R + (where & 63)));
+            };
+            if (colA >= 0) atomicMax(a.stripKeys + base + lane, key(target2 & 0xffffu, colA));
+            if (colB >= 0) atomicMax(a.stripKeys + base + kLanes + lane, key(target2 >> 16, colB));
+            continue;
+        }
         const int lo = (int)(best & 0xffffu) >> kBits, hi = (int)(best >> 16) >> kBits;
         if constexpr (LOC) {
             // first maximum in column-major order over the strips: highest score, then smallest column,
@@ -1757,12 +1811,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
     }
 }
 
-template <int R, bool LOC>
+template <int R, bool LOC, bool KNOWN = false>
 static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
     const size_t lds = PairLayout<R>::bytes(a.nSymbols) + 16 + kPaceInts * sizeof(int);  // table + the unit in flight + pacing
     static uint64_t configured = 0;  // one bit per device
     if (firstUseOnThisDevice(&configured)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R, LOC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&interseq_pair_strips_kernel<R, LOC, KNOWN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             int dev = 0;
@@ -1773,33 +1827,35 @@ static hipError_t launchPairStripsR(const InterseqArgs& a, int computeUnits, hip
     }
     const int nBatches = (a.nGroups + a.batchGroups - 1) / a.batchGroups;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(computeUnits, (int64_t)nBatches * a.nStrips));
-    hipLaunchKernelGGL((interseq_pair_strips_kernel<R, LOC>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
+    hipLaunchKernelGGL((interseq_pair_strips_kernel<R, LOC, KNOWN>), dim3(blocks), dim3(kPairWaves * kLanes), lds, stream, a);
     return hipGetLastError();
 }
 
 constexpr int kStripsMaxRows = 52;      // taller strips spill (the boundary rows cost 9 registers)
 constexpr int kStripsMaxRowsLoc = 48;   // with end locations
-static_assert(kStripsMaxRows == kPairStripsMaxRows && kStripsMaxRowsLoc == kPairStripsMaxRowsLoc, "common.h mirrors these");
-template <int kLo, int kStep, bool LOC>
+constexpr int kStripsMaxRowsKnown = 40; // second pass of an `end` search (a row scan inside the column loop)
+static_assert(kStripsMaxRows == kPairStripsMaxRows && kStripsMaxRowsLoc == kPairStripsMaxRowsLoc &&
+              kStripsMaxRowsKnown == kPairStripsMaxRowsKnown, "common.h mirrors these");
+template <int kLo, int kStep, bool LOC, bool KNOWN>
 static hipError_t launchPairStripsCase(const InterseqArgs& a, int computeUnits, hipStream_t stream) {
-    if constexpr (kLo + kStep <= (LOC ? kStripsMaxRowsLoc : kStripsMaxRows))
-        return launchPairStripsR<kLo + kStep, LOC>(a, computeUnits, stream);
+    if constexpr (kLo + kStep <= (KNOWN ? kStripsMaxRowsKnown : LOC ? kStripsMaxRowsLoc : kStripsMaxRows))
+        return launchPairStripsR<kLo + kStep, LOC, KNOWN>(a, computeUnits, stream);
     else return hipErrorInvalidValue;
 }
-template <int kLo, bool LOC>
+template <int kLo, bool LOC, bool KNOWN = false>
 static hipError_t launchPairStrips(const InterseqArgs& a, int rowsPerStrip, int computeUnits, hipStream_t stream) {
     if (a.nStrips < 2 || !a.unitCounter || !a.unitFlags || !a.boundary[0] || !a.boundary[1] || a.batchGroups < 1 ||
-        a.batchGroups > kPairWaves || (LOC && !a.stripKeys))
+        a.batchGroups > kPairWaves || ((LOC || KNOWN) && !a.stripKeys) || (KNOWN && !a.known))
         return hipErrorInvalidValue;
     switch (rowsPerStrip - kLo) {
-        case 0: return launchPairStripsCase<kLo, 0, LOC>(a, computeUnits, stream);
-        case 2: return launchPairStripsCase<kLo, 2, LOC>(a, computeUnits, stream);
-        case 4: return launchPairStripsCase<kLo, 4, LOC>(a, computeUnits, stream);
-        case 6: return launchPairStripsCase<kLo, 6, LOC>(a, computeUnits, stream);
-        case 8: return launchPairStripsCase<kLo, 8, LOC>(a, computeUnits, stream);
-        case 10: return launchPairStripsCase<kLo, 10, LOC>(a, computeUnits, stream);
-        case 12: return launchPairStripsCase<kLo, 12, LOC>(a, computeUnits, stream);
-        case 14: return launchPairStripsCase<kLo, 14, LOC>(a, computeUnits, stream);
+        case 0: return launchPairStripsCase<kLo, 0, LOC, KNOWN>(a, computeUnits, stream);
+        case 2: return launchPairStripsCase<kLo, 2, LOC, KNOWN>(a, computeUnits, stream);
+        case 4: return launchPairStripsCase<kLo, 4, LOC, KNOWN>(a, computeUnits, stream);
+        case 6: return launchPairStripsCase<kLo, 6, LOC, KNOWN>(a, computeUnits, stream);
+        case 8: return launchPairStripsCase<kLo, 8, LOC, KNOWN>(a, computeUnits, stream);
+        case 10: return launchPairStripsCase<kLo, 10, LOC, KNOWN>(a, computeUnits, stream);
+        case 12: return launchPairStripsCase<kLo, 12, LOC, KNOWN>(a, computeUnits, stream);
+        case 14: return launchPairStripsCase<kLo, 14, LOC, KNOWN>(a, computeUnits, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -602,15 +602,23 @@ def test_strips_end_locations_range_is_left_and_lanes_are_redone(capi, monkeypat
 
 def test_strips_end_locations_probe_declines_scores_in_the_thousands(capi):
     # long query, long targets, cheap gaps: random pairs score far beyond 384. The twelve longest groups
-    # go through the scores-only kernel first and the search is left to the general kernel; under the
-    # usual gap costs the same search stays on the strips kernel. (Sizes at which the host picks the
-    # strips kernel by itself; the general kernel's own answer is the reference, the checker on a sample.)
+    # go through the scores-only kernel first; since round 3 the search then takes TWO sweeps of the strips
+    # kernel (scores, then the first cell that holds each score) instead of the general kernel's row scans
+    # (MIOPAL_NO_TWO_PASS_ENDS restores them); under the usual gap costs the same search stays on the row
+    # keys. (Sizes at which the host picks the strips kernel by itself; the general kernel's own answer is
+    # the reference, the checker on a sample.)
     rng = np.random.default_rng(74)
     query = _data.random_protein(rng, 600)
     res, off = _data.random_db(rng, np.full(90_000, 600))
     db = capi.DeviceDatabase(res, off, 24)
     try:
-        for go, ge, want in ((3, 1, 1), (11, 1, PAIR_STRIPS)):
+        os.environ["MIOPAL_NO_TWO_PASS_ENDS"] = "1"
+        try:
+            db.search(query, B62, 3, 1, "end", "sw")
+            assert (capi.DeviceDatabase.last_routing()[1] & 31) == 1
+        finally:
+            del os.environ["MIOPAL_NO_TWO_PASS_ENDS"]
+        for go, ge, want in ((3, 1, PAIR_STRIPS), (11, 1, PAIR_STRIPS)):
             got = db.search(query, B62, go, ge, "end", "sw")
             assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (go, ge)
             ref = _oracle.search(query, res[:off[100]], off[:101], B62, go, ge, "end", "sw")
@@ -625,3 +633,39 @@ def test_strips_end_locations_probe_declines_scores_in_the_thousands(capi):
                 np.testing.assert_array_equal(got[key], general[key], err_msg=f"{go}/{ge} {key}: every target")
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("qlen", [65, 97, 130, 193, 333, 700])
+def test_strips_end_locations_in_two_sweeps(capi, qlen, monkeypatch):
+    # the second form of multi-strip end locations (scores beyond the row keys' range): a scores-only sweep,
+    # then a sweep that looks for each target's known score - first column, then first row, over all strips;
+    # targets without a positive cell, ties across strips and columns, lanes beyond 25600 (redone), `full`
+    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    monkeypatch.setenv("MIOPAL_TWO_PASS_ENDS", "1")
+    rng = np.random.default_rng(9000 + qlen)
+    query = _data.random_protein(rng, qlen)
+    seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]
+    for k in range(24):
+        a = int(rng.integers(0, max(1, qlen - 20)))
+        piece = _data.mutate(rng, query[a:a + int(rng.integers(12, 60))], 0.1)
+        seqs.append(np.concatenate([_data.random_protein(rng, int(rng.integers(0, 40))), piece,
+                                    _data.random_protein(rng, int(rng.integers(0, 40)))]))
+    seqs += [query[: qlen // 2], query[qlen // 3:], np.zeros(0, dtype=np.uint8), query[-5:], query.copy()]
+    res, off = _oracle.flatten(seqs)
+    strips_end_check(capi, query, res, off, B62, 3, 1, modes=("end", "full"), tag=f"two sweeps Q={qlen}")
+    # ties: a block repeated in the query, once and twice in the targets (smallest column, then smallest row)
+    block = _data.random_protein(rng, 30)
+    rep = np.concatenate([block, _data.random_protein(rng, 14)] * 8)[:qlen]
+    seqs2 = [_data.random_protein(rng, int(n)) for n in rng.integers(20, 300, size=100)]
+    for k in range(20):
+        pre, mid, post = (_data.random_protein(rng, int(rng.integers(0, 50))) for _ in range(3))
+        seqs2 += [np.concatenate([pre, block, post]), np.concatenate([pre, block, mid, block, post])]
+    res2, off2 = _oracle.flatten(seqs2)
+    strips_end_check(capi, rep, res2, off2, scaled_identity(24, 5, -4), 6, 2, tag="two sweeps, repeats")
+    # scores beyond the lanes' own range (25600): those lanes are redone by the int32 kernel
+    m = scaled_identity(24, 500, -300)
+    seqs3 = [_data.random_protein(rng, int(n)) for n in rng.integers(10, 300, size=200)]
+    seqs3 += [np.concatenate([_data.random_protein(rng, 11), query[at:at + k], _data.random_protein(rng, 5)])
+              for k in (60, 52, 51, 50, 30) for at in (0, 37) if at + k <= qlen]
+    res3, off3 = _oracle.flatten(seqs3)
+    strips_end_check(capi, query, res3, off3, m, 700, 100, tag="two sweeps, match 500")
