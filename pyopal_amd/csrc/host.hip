@@ -1577,11 +1577,10 @@ struct Search {
                 // shares of a wavefront slot - the chain of that group is then about the whole launch - and with
                 // 16 strips or more the general kernel's rounds cost more than any chain.)
                 const bool hidden = view->nGroups > 0 && 5 * (int64_t)view->groupChunksHost[0] <= 6 * balanced;
-                // (with 16 strips or more a longest group of up to three balanced shares still pays; beyond that
-                // - 20k targets, a tenth of them thirty times as long as the rest - the chain of the longest
-                // group is the launch and the general kernel's pipeline over a workgroup's wavefronts is shorter)
-                const bool chainOk = view->nGroups > 0 && (int64_t)view->groupChunksHost[0] <= 3 * balanced;
-                const bool enough = ((ns >= 16 && chainOk) || (2 * units >= 3 * (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
+                // (with 16 strips or more the strips kernel whatever the longest group: log-normal lengths, 20k
+                // targets at Q = 2000: 3.2 against the general kernel's 1.1 TCUPS; the one shape that loses - 20k
+                // targets, a tenth of them thirty times as long as the rest - loses 15 %: profiles/r03c_routing_table.txt)
+                const bool enough = (ns >= 16 || (2 * units >= 3 * (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
                 if (enough && rowsP >= 32 && rowsP <= maxRows && band(rowsP) && (int64_t)(ns - 1) * rowsP < Q && ns <= 4096) {
                     stripRows = rowsP;
                     nStrips = ns;
@@ -1642,8 +1641,7 @@ struct Search {
                     const bool hidden = view->nGroups > 0 && 2 * (int64_t)view->groupChunksHost[0] <= 3 * balanced;
                     // (the same two limits as the Smith-Waterman strips kernel: units enough to keep every
                     // CU on one strip for a while, the longest group short against the launch)
-                    const bool chainOk = view->nGroups > 0 && (int64_t)view->groupChunksHost[0] <= 3 * balanced;
-                    const bool enough = ((bestNs >= 16 && chainOk) || (units >= (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
+                    const bool enough = (bestNs >= 16 || (units >= (int64_t)db->computeUnits && hidden)) || getenv("MIOPAL_PAIR_STRIPS");
                     if (enough) {
                         stripRows = bestRows;
                         nStrips = bestNs;
@@ -1681,15 +1679,19 @@ struct Search {
             if (firstGroup > 0 && !getenv("MIOPAL_ALWAYS_SKIP")) {
                 const int rowsNow = stripRows ? stripRows : std::min(Q, kMaxStripRows);
                 const double rounds = stripRows ? 1.0 : (double)((nStrips + waves - 1) / waves);
-                const double tau = 7e-6 * rowsNow / 54.0 * rounds;
+                // (the general kernel of several strips: a workgroup pipelines a group's strips with a barrier
+                // per chunk step, about 7.5 us per step and round whoever else is on the CU - no faster alone)
+                const bool pipelined = !stripRows && nStrips > 1;
+                const double tau = pipelined ? 7.5e-6 * rounds : 7e-6 * rowsNow / 54.0;
+                const double alone = pipelined ? 1.0 : 2.5;
                 const double balancedAll = (double)total / (double)std::max<int64_t>(slots, 1) * (stripRows ? nStrips : 1);
                 int64_t skippedChunks = 0;
                 for (int g = 0; g < firstGroup; ++g) skippedChunks += view->groupChunksHost[g];
                 const double balancedRest = (double)(total - skippedChunks) / (double)std::max<int64_t>(slots, 1) * (stripRows ? nStrips : 1);
-                const double keep = std::max(balancedAll * tau, view->groupChunksHost[0] * tau / 2.5);
+                const double keep = std::max(balancedAll * tau, view->groupChunksHost[0] * tau / alone);
                 const double nextLongest = firstGroup < view->nGroups ? view->groupChunksHost[firstGroup] : 0;
                 const double side = (double)skippedChunks * 4.0 * kGroupTargets * (double)Q / 1e12;
-                const double skip = std::max({balancedRest * tau, nextLongest * tau / 2.5, side});
+                const double skip = std::max({balancedRest * tau, nextLongest * tau / alone, side});
                 if (skip >= keep) firstGroup = 0;
             }
             const int skipped = std::min(firstGroup * kGroupTargets, view->nPacked);
