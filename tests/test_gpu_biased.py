@@ -503,7 +503,8 @@ def test_strips_routing_by_size(capi):
     res, off = _data.random_db(rng, np.full(100_000, 100))
     db = capi.DeviceDatabase(res, off, 24)
     try:
-        for qlen, lo, hi, want in ((100, 0, 100_000, 1), (100, 0, 3000, 1), (600, 0, 100_000, PAIR_STRIPS), (900, 0, 3000, 1)):
+        for qlen, lo, hi, want in ((100, 0, 100_000, 1), (100, 0, 3000, 1), (600, 0, 100_000, PAIR_STRIPS), (300, 0, 3000, 1),
+                                   (900, 0, 3000, PAIR_STRIPS)):   # (16 strips or more: the strips kernel whatever the size)
             q = _data.random_protein(rng, qlen)
             got = db.search(q, B62, 11, 1, "score", "sw", lo, hi)["score"]
             assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (qlen, hi)

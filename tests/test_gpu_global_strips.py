@@ -180,14 +180,14 @@ def test_few_groups_long_query(capi, forced):
 
 
 def test_routing(capi):
-    # few (group, strip) units: the general kernel; many: the strips kernel; a query beyond the static
+    # few (group, strip) units: the general kernel; many, or 16 strips and more: the strips kernel; a query beyond the static
     # range of the patterns (Q (max S + ext) above 0x7C00): the general kernel; the switch
     rng = np.random.default_rng(75)
     res, off = _data.random_db(rng, np.full(100_000, 100))
     db = capi.DeviceDatabase(res, off, 24)
     try:
-        for qlen, lo, hi, want in ((100, 0, 100_000, 1), (600, 0, 100_000, GLOBAL_STRIPS), (900, 0, 3000, 1),
-                                   (2600, 0, 100_000, 1)):
+        for qlen, lo, hi, want in ((100, 0, 100_000, 1), (600, 0, 100_000, GLOBAL_STRIPS), (300, 0, 3000, 1),
+                                   (900, 0, 3000, GLOBAL_STRIPS), (2600, 0, 100_000, 1)):
             q = _data.random_protein(rng, qlen)
             for algo in ALGOS:
                 got = db.search(q, B62, 11, 1, "score", algo, lo, hi)["score"]
