@@ -378,6 +378,7 @@ struct Workspace {
 struct View {
     int64_t start = 0, end = 0;
     int overlap = 0;                 // > 0: long targets are cut into windows overlapping by this much
+    int stride = 0;                  // ... starting every `stride` residues
     int32_t* d_segStart = nullptr;   // view position -> first residue of its window (segmented views)
     int nPacked = 0;                 // targets in the packed groups
     int nGroups = 0;
@@ -421,7 +422,7 @@ struct MiopalDb {
 
     struct ViewSlot {
         int64_t start, end;
-        int overlap;
+        int overlap, stride;
         bool building;                 // placeholder: the view is being built outside the lock
         std::shared_ptr<View> view;
     };
@@ -879,7 +880,8 @@ int finishView(MiopalDb* db, View* v);
 // packNow = false: everything but the pack kernel (which reads the residues on the device): the lists,
 // the device blocks and the upload of the small arrays - what can be done while the residues are still
 // crossing PCIe; finishView() packs.
-int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, bool packNow = true) {
+int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, bool packNow = true,
+              int strideWanted = -1) {
     if (packNow) {
         // (lists of this very slice built ahead, beside the upload of the residues: only the packing is left)
         std::shared_ptr<View> ready;
@@ -906,7 +908,8 @@ int buildView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared
     // in order), in slices of the target range worked on side by side: count, place, scatter. For
     // a million targets the lists used to cost more than the search itself.
     const int64_t nT = end - start;
-    const int stride = overlap > 0 ? segmentStride(overlap) : 0, window = stride + overlap;
+    const int stride = overlap > 0 ? (strideWanted > 0 ? strideWanted : segmentStride(overlap)) : 0, window = stride + overlap;
+    v->stride = stride;
     const int nSlices = hostThreads((size_t)nT, 65536);
     auto sliceLo = [&](int t) { return start + nT * t / nSlices; };
     auto windowsOf = [&](int L) {   // windows until the tail is inside the overlap of the previous one
@@ -1119,12 +1122,13 @@ void evictViews(MiopalDb* db, size_t budget, size_t keepCount) {
 // worker threads threw) - the placeholder is gone and its waiters are woken when this returns: a
 // placeholder left behind would block every later search of the same slice forever.
 template <class Build>
-int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, const Build& build) {
+int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, const Build& build,
+                int stride = 0) {
     std::unique_lock<std::mutex> lk(db->viewMutex);
     for (;;) {
         auto it = db->views.begin();
         for (; it != db->views.end(); ++it)
-            if (it->start == start && it->end == end && it->overlap == overlap) break;
+            if (it->start == start && it->end == end && it->overlap == overlap && it->stride == stride) break;
         if (it == db->views.end()) break;
         if (!it->building) {
             *out = it->view;
@@ -1133,7 +1137,7 @@ int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shar
         }
         db->viewReady.wait(lk);   // somebody is building this very view
     }
-    db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, true, nullptr});
+    db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, stride, true, nullptr});
     lk.unlock();
     std::shared_ptr<View> v;
     auto guardedBuild = [&]() -> int {
@@ -1160,14 +1164,14 @@ int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shar
     lk.lock();
     auto mine = db->views.begin();
     for (; mine != db->views.end(); ++mine)
-        if (mine->building && mine->start == start && mine->end == end && mine->overlap == overlap) break;
+        if (mine->building && mine->start == start && mine->end == end && mine->overlap == overlap && mine->stride == stride) break;
     if (rc != 0) {
         if (mine != db->views.end()) db->views.erase(mine);
         db->viewReady.notify_all();
         return rc;
     }
     if (mine == db->views.end()) {   // (cannot happen: placeholders are only removed by their builder)
-        db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, false, v});
+        db->views.push_front(MiopalDb::ViewSlot{start, end, overlap, stride, false, v});
     } else {
         mine->view = v;
         mine->building = false;
@@ -1179,9 +1183,9 @@ int getViewWith(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shar
     return 0;
 }
 
-int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out) {
+int getView(MiopalDb* db, int64_t start, int64_t end, int overlap, std::shared_ptr<View>* out, int stride = 0) {
     return getViewWith(db, start, end, overlap, out,
-                       [&](std::shared_ptr<View>* v) { return buildView(db, start, end, overlap, v); });
+                       [&](std::shared_ptr<View>* v) { return buildView(db, start, end, overlap, v, true, stride); }, stride);
 }
 
 // ---- one search ----------------------------------------------------------------
@@ -1464,8 +1468,21 @@ struct Search {
                 keyBias = 1 << 22;   // scores above -2^22 in the key's 24-bit score field
             }
         }
+        // Window stride. The overlap is what correctness needs; the stride only trades the length of a window
+        // (a group of long targets is a chain of stride + overlap columns) against the work done twice (every
+        // window repeats `overlap` columns: at the shortest stride, 0.6 overlap, a long target costs 2.7 times
+        // its cells). When long targets are the bulk of the database rather than its tail - a tenth of 2M
+        // targets thirty times as long as the rest: 5.3 TCUPS for Smith-Waterman at Q = 53 where NW, which
+        // cannot cut them, ran at 9.6 - a window may be as long as 1.5 balanced shares of a wavefront slot.
+        int stride = overlap > 0 ? segmentStride(overlap) : 0;
+        if (overlap > 0 && !getenv("MIOPAL_SHORT_STRIDE")) {
+            const double share = db->count > 0 ? (double)n / (double)db->count : 1.0;
+            const double balancedColumns = (double)db->total * share / ((double)kGroupTargets * 12.0 * db->computeUnits);
+            const int64_t want = (int64_t)(1.5 * balancedColumns) - overlap;
+            if (want > stride) stride = (int)std::min<int64_t>((want + 255) / 256 * 256, 8192);
+        }
         std::shared_ptr<View> view;
-        RC_TRY(getView(db, start, end, overlap, &view));
+        RC_TRY(getView(db, start, end, overlap, &view, stride));
         spt.mark("    view lookup");
         // not handled by the packed kernel: can be recomputed beside it
         std::vector<PairJob> sideJobs;
@@ -1667,7 +1684,7 @@ struct Search {
             // Q = 150: keeping the longest group in the packed kernel costs 5.6 ms against 4.0)
             int64_t limit = std::max<int64_t>(5 * (total / std::max<int64_t>(slots, 1)) / 2, 128);
             // windows of a segmented view are as short as a group of long targets can get
-            if (overlap > 0) limit = std::max<int64_t>(limit, (segmentStride(overlap) + overlap + 3) / 4);
+            if (overlap > 0) limit = std::max<int64_t>(limit, (stride + overlap + 3) / 4);
             while (firstGroup < view->nGroups && view->groupChunksHost[firstGroup] > limit) ++firstGroup;
             // ... unless the groups above the limit ARE the search (round 3: a tenth of 500k targets thirty
             // times as long as the rest - 391 groups of 3000 columns hold three quarters of the cells, all of
