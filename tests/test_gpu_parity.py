@@ -638,6 +638,12 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
             finally:
                 if switch:
                     del os.environ[switch]
+        # a result array that starts INSIDE a pinned allocation: the kernel must write at that address
+        big = torch.empty(3 * 9000, dtype=torch.int32).pin_memory().numpy()
+        big[:] = -7
+        db.search(query, B62, 3, 1, "score", "sw", score_out=big[9000:18000])
+        np.testing.assert_array_equal(big[9000:18000], want)
+        assert (big[:9000] == -7).all() and (big[18000:] == -7).all()
         with pytest.raises(ValueError):
             db.search(query, B62, 3, 1, "score", "sw", score_out=np.empty(5, dtype=np.int32))
     finally:
