@@ -60,6 +60,8 @@ struct InterseqArgs {
     // one-strip biased Smith-Waterman kernel, scores only: results straight into database order (no view-order
     // array, no scatter kernel); directOut may be pinned host memory (miopalSearch: no D2H copy either)
     int32_t* directOut;        // already offset by - sliceStart: entry directIds[view position]; null: a.score
+    int32_t* directEndI;       // with end locations: the same for the query / target coordinate of the answer
+    int32_t* directEndJ;
     const int32_t* directIds;  // view position -> database index
     int directN;               // view positions that hold a target
     int stripSpinCap;          // strips kernels: polls (x s_sleep) before a unit gives up on the strip above; 0 = the default

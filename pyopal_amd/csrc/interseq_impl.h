@@ -1363,12 +1363,26 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_biased_kern
         }
         const int lo = (int)(best & 0xffffu) >> kBits, hi = (int)(best >> 16) >> kBits;
         const size_t base = (size_t)g * kGroupTargets;
-        if (!LOC && a.directOut) {
+        if (a.directOut) {
             // database order at once (the host has made sure that no lane can leave its range and that
             // nothing else writes these results): no view-order array, no scatter kernel
             const int posA = (int)base + lane, posB = posA + kLanes;
-            if (posA < a.directN) a.directOut[a.directIds[posA]] = lo;
-            if (posB < a.directN) a.directOut[a.directIds[posB]] = hi;
+            if (posA < a.directN) {
+                const int id = a.directIds[posA];
+                a.directOut[id] = lo;
+                if constexpr (LOC) {
+                    a.directEndI[id] = colA < 0 ? -1 : kRowMask - (int)(best & kRowMask);
+                    a.directEndJ[id] = colA;
+                }
+            }
+            if (posB < a.directN) {
+                const int id = a.directIds[posB];
+                a.directOut[id] = hi;
+                if constexpr (LOC) {
+                    a.directEndI[id] = colB < 0 ? -1 : kRowMask - (int)((best >> 16) & kRowMask);
+                    a.directEndJ[id] = colB;
+                }
+            }
             continue;
         }
         a.score[base + lane] = lo;

@@ -619,6 +619,7 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
     query = _oracle.encode(_data.README_QUERY)
     res, off = _data.random_db(rng, rng.integers(1, 400, size=9000))
     want = _oracle.search_parallel(query, res, off, B62, 3, 1, "score", "sw")["score"]
+    want_end = _oracle.search_parallel(query, res, off, B62, 3, 1, "end", "sw")
     db = capi.DeviceDatabase(res, off, 24)
     try:
         pinned = torch.empty(9000, dtype=torch.int32).pin_memory().numpy()
@@ -630,6 +631,10 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
                 for lo, hi in ((0, 9000), (1, 9000), (4000, 4001), (137, 8999)):
                     got = db.search(query, B62, 3, 1, "score", "sw", lo, hi)["score"]
                     np.testing.assert_array_equal(got, want[lo:hi], err_msg=f"{switch} [{lo},{hi})")
+                    # (end locations leave the kernel the same way: three arrays)
+                    ends = db.search(query, B62, 3, 1, "end", "sw", lo, hi)
+                    for key in ("score", "end_q", "end_t"):
+                        np.testing.assert_array_equal(ends[key], want_end[key][lo:hi], err_msg=f"{switch} [{lo},{hi}) end {key}")
                     for buf in (plain, pinned):
                         buf[:] = -7
                         db.search(query, B62, 3, 1, "score", "sw", lo, hi, score_out=buf[: hi - lo])
