@@ -2122,6 +2122,27 @@ __global__ __launch_bounds__(globalWaves(R) * kLanes) void interseq_pair_global_
             if (crowA >= 0 && (colA < 0 || cbA > runA)) { runA = cbA; rowA = crowA; colA = lenA - 1; }
             if (crowB >= 0 && (colB < 0 || cbB > runB)) { runB = cbB; rowB = crowB; colB = lenB - 1; }
         }
+        if (a.directOut) {
+            // database order at once (nothing else writes these results: see the Smith-Waterman kernel)
+            const int posA = (int)base + lane, posB = posA + kLanes;
+            if (posA < a.directN) {
+                const int id = a.directIds[posA];
+                a.directOut[id] = runA;
+                if (locate) {
+                    a.directEndI[id] = rowA;
+                    a.directEndJ[id] = colA;
+                }
+            }
+            if (posB < a.directN) {
+                const int id = a.directIds[posB];
+                a.directOut[id] = runB;
+                if (locate) {
+                    a.directEndI[id] = rowB;
+                    a.directEndJ[id] = colB;
+                }
+            }
+            continue;
+        }
         a.score[base + lane] = runA;
         a.score[base + kLanes + lane] = runB;
         if (locate) {
