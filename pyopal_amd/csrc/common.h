@@ -139,6 +139,7 @@ struct WalkArgs {
     int64_t headDirStride;
     int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
     int queryLength;          // whole query (staged in LDS when it fits)
+    int dirPlanes;            // lane-major directions are perpair_profile_kernel's bit planes
 };
 
 // perpair_kernel: one lane per (query window, target window) pair of a one-strip query
@@ -162,8 +163,16 @@ struct PerPairArgs {
     int64_t boundaryStride;   // columns per 64 consecutive jobs (>= longest target window)
     const int* skipWaves;     // hybrid direction pass: the first *skipWaves wavefronts' jobs belong to
                               // intraseq_kernel (null: none)
+    // > 0: perpair_profile_kernel (regions kAllCells and kPerPairTrace only): bytes per residue row of its
+    // query profile in LDS (perPairProfileBytes); every job walks the query the same way (`reversed`), and
+    // the directions leave as bit planes: [job / 64][strip][j][rows 0-31 | 32-63][plane][job % 64] dwords
+    int profileStride;
+    int reversed;
+    int64_t residueCount;     // bytes at `residues` (the profile kernel reads them four at a time, clamped; >= 4)
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
+// LDS bytes of the profile kernel for this query (0: too long for it), and the stride to pass
+size_t perPairProfileBytes(int queryLength, int alphabet, int* stride);
 
 struct PackArgs {
     const uint8_t* residues;
@@ -294,6 +303,8 @@ hipError_t launchDecodeKeys(const unsigned long long* keys, int n, int32_t* scor
                             hipStream_t stream, int scoreBias = 0);
 hipError_t launchFillInt32(int32_t* out, int n, int32_t value, hipStream_t stream);
 // subset of a resident database: dst[dstOff[k] ...] = src[srcStart[k] ...] for every sequence k (dstOff has n + 1 entries)
+// device -> pinned host copy by a small kernel of our own (see pack.hip)
+hipError_t launchCopyOut(const void* src, void* dst, int64_t bytes, hipStream_t stream);
 hipError_t launchGatherSequences(const uint8_t* src, const int64_t* srcStart, const int64_t* dstOff, int64_t n,
                                  uint8_t* dst, hipStream_t stream);
 // takeMax: several view positions (segments) may belong to one target; `out` starts at 0

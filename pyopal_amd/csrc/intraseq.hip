@@ -485,6 +485,8 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
     const uint8_t* dirs = head ? a.headDirs + (int64_t)idx * a.headDirStride
                         : laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
                                     : a.dirs + job.dirOff;
+    const bool planes = laneMajor && a.dirPlanes;
+    const uint32_t* planeBase = reinterpret_cast<const uint32_t*>(a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride) + (idx & 63);
     const uint8_t* q = a.query + job.qOff;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
     const int slot = a.slotByOut ? job.out : idx;
@@ -514,10 +516,25 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
             break;
         }
         const int l = i & 63;
-        // perpair_kernel's layout holds two rows per byte ([strip][column][row pair][lane])
-        const uint8_t d = laneMajor
-            ? (uint8_t)((dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * (kLanes / 2) + (l >> 1)) * kLanes] >> ((l & 1) * 4)) & 0xf)
-            : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
+        uint8_t d;
+        if (planes) {
+            // perpair_profile_kernel: bit planes of 32 rows, [strip][column][half][plane][lane] dwords. Most steps
+            // of a path are diagonal: the "from the diagonal" plane first, the "from E" plane only off it; inside a
+            // gap the "opened" plane of that gap
+            const uint32_t* at = planeBase + (((int64_t)(i >> 6) * a.dirStripColumns + j) * 2 + (l >> 5)) * 4 * kLanes;
+            const int bit = 31 - (l & 31);
+            if (state == 0) {
+                d = 0;
+                if (((at[0] >> bit) & 1u) == 0) d = (uint8_t)(((at[kLanes] >> bit) & 1u) ? 1u : 2u);
+            } else {
+                d = (uint8_t)(((at[(state + 1) * kLanes] >> bit) & 1u) ? 12u : 0u);
+            }
+        } else {
+            // perpair_kernel's layout holds two rows per byte ([strip][column][row pair][lane])
+            d = laneMajor
+                ? (uint8_t)((dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * (kLanes / 2) + (l >> 1)) * kLanes] >> ((l & 1) * 4)) & 0xf)
+                : dirs[((size_t)(i >> 6) * nSteps + (j + l)) * kLanes + l];
+        }
         if (state == 0) {
             const int c = d & 3;
             if (c == 0) {
@@ -785,18 +802,23 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
 }
 
 // Scatter: a block ranks its jobs per length in LDS and reserves one range per (block, length)
-// with a single global atomic, instead of one contended atomic per job.
+// with a single global atomic, instead of one contended atomic per job. The 56-byte jobs are then copied
+// dword by dword with neighbouring lanes on neighbouring dwords of the same job (a thread writing its own
+// job made 64 separate partial-line writes of every store instruction: 0.2 ms per 250k jobs).
+constexpr int kJobWords = sizeof(PairJob) / 4;
+static_assert(sizeof(PairJob) % 4 == 0, "PairJob is copied as dwords");
+
 __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const PairJob* jobs, int n, int maxLen,
                                                                         int shift, int* bins, PairJob* sorted) {
     extern __shared__ int local[];
+    __shared__ int dest[kSortBlock];
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
     __syncthreads();
-    const int k = blockIdx.x * kSortBlock + threadIdx.x;
-    PairJob j{};
+    const int64_t base = (int64_t)blockIdx.x * kSortBlock;
+    const int64_t k = base + threadIdx.x;
     int key = 0, rank = 0;
     if (k < n) {
-        j = jobs[k];
-        key = min(j.tLen >> shift, maxLen);
+        key = min(jobs[k].tLen >> shift, maxLen);
         rank = atomicAdd(&local[key], 1);
     }
     __syncthreads();
@@ -805,7 +827,15 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
         if (c) local[b] = atomicAdd(&bins[b], c);
     }
     __syncthreads();
-    if (k < n) sorted[local[key] + rank] = j;
+    dest[threadIdx.x] = local[key] + rank;
+    __syncthreads();
+    const int here = (int)min<int64_t>(kSortBlock, n - base);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(jobs + base);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(sorted);
+    for (int t = threadIdx.x; t < here * kJobWords; t += kSortBlock) {
+        const int job = t / kJobWords, word = t - job * kJobWords;
+        dst[(int64_t)dest[job] * kJobWords + word] = src[t];
+    }
 }
 
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,

@@ -171,6 +171,31 @@ __global__ __launch_bounds__(256) void gather_sequences_kernel(const uint8_t* sr
     for (int64_t p = lane; p < len; p += 64) dst[to + p] = src[from + p];
 }
 
+// Device memory to pinned host memory beside a running search: the runtime's copy on this pool is a
+// shader kernel that fills the chip (a direction kernel of 0.49 ms lasted 0.78 ms with a 0.34-ms copy
+// beside it: its wavefronts take the registers of one of the two wavefronts a SIMD could hold); this one
+// keeps to 64 small workgroups - PCIe needs a few hundred KB in flight, not the chip. src and dst are
+// equally aligned (mod 16).
+__global__ __launch_bounds__(256) void copy_out_kernel(const uint8_t* src, uint8_t* dst, int64_t bytes) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, all = (int64_t)gridDim.x * blockDim.x;
+    const int64_t head = std::min<int64_t>(bytes, (16 - (int64_t)(reinterpret_cast<uintptr_t>(dst) & 15)) & 15);
+    const int64_t body = (bytes - head) / 16;
+    const uint4* s16 = reinterpret_cast<const uint4*>(src + head);
+    uint4* d16 = reinterpret_cast<uint4*>(dst + head);
+    for (int64_t k = tid; k < body; k += all) d16[k] = s16[k];
+    const int64_t tail0 = head + body * 16;
+    if (tid < head) dst[tid] = src[tid];
+    if (tid < bytes - tail0) dst[tail0 + tid] = src[tail0 + tid];
+}
+
+hipError_t launchCopyOut(const void* src, void* dst, int64_t bytes, hipStream_t stream) {
+    if (bytes <= 0) return hipSuccess;
+    if (((reinterpret_cast<uintptr_t>(src) ^ reinterpret_cast<uintptr_t>(dst)) & 15) != 0)
+        return hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, stream);
+    hipLaunchKernelGGL(copy_out_kernel, dim3(64), dim3(256), 0, stream, (const uint8_t*)src, (uint8_t*)dst, bytes);
+    return hipGetLastError();
+}
+
 __global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = value;

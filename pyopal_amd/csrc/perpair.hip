@@ -221,11 +221,286 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
     }
 }
 
+// ---- the same two passes with a query profile and columns on a sliding scale -----------------
+// What the kernel above spends per cell: three instructions on the substitution score (row offset,
+// address, LDS read), two per gap state, three on the candidate test. Here:
+//   * the scores come from a QUERY PROFILE in LDS, prof[t][y] = matrix[query(y)][t] + open as a
+//     signed byte, y running along the lane's walk of the query (reversed for the start-cell scan):
+//     one aligned dword read + one v_alignbyte give four rows of the lane, and the byte is sign-
+//     extended inside the add (SDWA);
+//   * column j is kept on the scale X' = X + j * ext: extending a horizontal gap costs nothing
+//     (E' = max(E', HM)), the vertical one subtracts once (F' = max(F', HM above) - ext), and
+//     HM = H' - (open - ext) opens both;
+//   * the scan keeps the column's maximum only; rows are compared when a lane meets its known
+//     optimum (once per lane), or - without one - when a column beats the running maximum;
+//   * the direction pass leaves four BIT PLANES per cell (came from the diagonal / from E / E was
+//     opened / F was opened), each shifted in with a subtraction + v_alignbit, stored as dwords of 32
+//     rows, lanes side by side: [pair / 64][strip][column][rows 0-31 | 32-63][plane][pair % 64]. The
+//     walk reads the "diagonal" plane and, off the diagonal, one more.
+// Same model and tie-breaks as perpair_kernel (the flags are the same comparisons).
+constexpr int kProfilePad = -128;
+
+// One flag of a cell shifted into its plane: `larger` is the maximum the flag asks about, `part` the
+// operand it may equal, so part - larger is negative exactly when they differ, and v_alignbit shifts
+// that sign bit in: two full-rate VALU instructions per flag and no SGPR in between (a compare into an
+// SGPR pair + add-with-carry took ~15 cycles each on gfx950, PMC: 8.4 cycles per VALU instruction for
+// the whole kernel). The planes collect 1 = differs; they are inverted when stored.
+__device__ __forceinline__ uint32_t shiftInDiffers(uint32_t plane, int larger, int part) {
+    return __builtin_amdgcn_alignbit(plane, (uint32_t)(part - larger), 31);
+}
+
+template <int MODE>  // kAllCells (start-cell scan) or kPerPairTrace (directions)
+__global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t prof[];
+    const int A = a.alphabet;
+    const int Qtot = a.queryLength;
+    const int pstride = a.profileStride;   // bytes per residue row, a multiple of 4, >= Qtot + 64 + 8
+    for (int idx = threadIdx.x; idx < (A + 1) * pstride; idx += kBlock) {
+        const int t = idx / pstride, y = idx - t * pstride;
+        int v = kProfilePad;
+        if (t < A && y < Qtot) v = a.matrix[(int)a.query[a.reversed ? Qtot - 1 - y : y] * A + t] + a.gapOpen;
+        prof[idx] = (int8_t)v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const bool active = idx < a.nJobs && !(a.skipWaves != nullptr && (idx >> 6) < *a.skipWaves);
+    PairJob job{};
+    if (active) job = a.jobs[idx];
+    const int Q = job.qLen, L = job.tLen;
+    const int open = a.gapOpen, ext = a.gapExt, c = open - ext;
+
+    int maxQ = Q, maxL = L;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        maxQ = max(maxQ, __shfl_xor(maxQ, off));
+        maxL = max(maxL, __shfl_xor(maxL, off));
+    }
+    maxQ = __builtin_amdgcn_readfirstlane(maxQ);
+    maxL = __builtin_amdgcn_readfirstlane(maxL);
+    const int nStrips = (maxQ + kLanes - 1) / kLanes;
+
+    int best = INT32_MIN, brow = -1, bcol = -1;
+    const bool stopOn = (job.rules & kRuleStop) != 0;
+    const int stopScore = job.stop;
+    int need = L;
+    const uint8_t* tptr = a.residues + job.tOff;
+    const int64_t tStep = job.tStep;
+    int2* bnd = a.boundary ? a.boundary + (int64_t)(idx >> 6) * a.boundaryStride * kLanes + lane : nullptr;
+    uint8_t* dirs = nullptr;
+    // (lanes side by side, one dword each: the walk reads one or two planes per step, and the pairs of a
+    // wavefront - sorted by length, walking back from similar cells - share its cache lines)
+    if (MODE == kPerPairTrace) dirs = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane * 4;
+    // the lane's first row along the profile
+    const int yBase = a.reversed ? Qtot - 1 - job.qOff : job.qOff;
+
+    for (int s = 0; s < nStrips; ++s) {
+        const int row0 = s * kLanes;
+        const int rowsHere = min(maxQ - row0, kLanes);  // wave-uniform
+        const bool toNext = s + 1 < nStrips;
+        // rows beyond the query read the pad bytes behind it (64 of them: a whole strip may)
+        const int ys = min(yBase + row0, Qtot);
+        const uint32_t shift = (uint32_t)ys & 3u;
+        const int yAligned = ys & ~3;
+        int HM[kLanes], E[kLanes];
+#pragma unroll
+        for (int i = 0; i < kLanes; ++i) {
+            HM[i] = row0 + i < Q ? borderGap(row0 + i, open, ext) - open : kNegInf;  // column -1 (on its own scale)
+            E[i] = kNegInf;
+        }
+        int sbest = INT32_MIN, srow = -1, scol = -1;
+        uint8_t* dcol = MODE == kPerPairTrace ? dirs + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes) : nullptr;
+        int aboveHmPrev = (s == 0 ? 0 : borderGap(row0 - 1, open, ext)) - open;
+        // bits of the rows a half strip really holds sit at the top of its planes
+        const int rows8 = (rowsHere + 7) & ~7;
+        const int pad0 = 32 - min(rows8, 32), pad1 = 32 - max(rows8 - 32, 0);
+
+        // The lane's target residues, four columns per load and four columns ahead (a wavefront holds two
+        // columns' worth of work per SIMD at most: a byte per column fetched one column ahead was waited for).
+        // The load is unconditional - its address clamped into the database - and what it returned is only
+        // put in place (column j0 in the lowest byte, the pad residue beyond the target) when it is needed.
+        const uint32_t padWord = (uint32_t)A * 0x01010101u;
+        const uint8_t* const dbLo = a.residues;
+        const uint8_t* const dbHi = a.residues + a.residueCount - 4;
+        auto wanted = [&](int j0) { return a.reversed ? tptr - j0 - 3 : tptr + j0; };
+        auto fetchRaw = [&](int j0) -> uint32_t {
+            const uint8_t* at = wanted(j0);
+            at = at < dbLo ? dbLo : at;
+            at = at > dbHi ? dbHi : at;
+            uint32_t w;
+            __builtin_memcpy(&w, at, 4);
+            return w;
+        };
+        auto inPlace = [&](uint32_t raw, int j0) -> uint32_t {
+            const uint8_t* at = wanted(j0);
+            const int64_t below = dbLo - at, above = at - dbHi;   // > 0: the clamp moved the load by this many bytes
+            uint32_t w = raw;
+            if (below > 0) w = below >= 4 ? 0u : raw << (8 * (int)below);
+            if (above > 0) w = above >= 4 ? 0u : raw >> (8 * (int)above);
+            if (a.reversed) w = __builtin_bswap32(w);
+            const int valid = L - j0;   // columns of the four that exist
+            const uint32_t keep = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : (1u << (8 * valid)) - 1u;
+            return (w & keep) | (padWord & ~keep);
+        };
+        uint32_t wcur = padWord, rawNext = fetchRaw(0);
+        int2 aboveNext = make_int2(0, 0);
+        if (s > 0) aboveNext = bnd[0];
+        int maxNeed = need;
+        if (MODE != kPerPairTrace) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) maxNeed = max(maxNeed, __shfl_xor(maxNeed, off));
+            maxNeed = __builtin_amdgcn_readfirstlane(maxNeed);
+        } else {
+            maxNeed = maxL;
+        }
+        int scale = 0;   // j * ext
+        for (int j = 0; j < maxNeed; ++j, scale += ext) {
+            if ((j & 3) == 0) {
+                wcur = inPlace(rawNext, j);
+                rawNext = fetchRaw(j + 4);
+            }
+            const int t = (int)((wcur >> (8 * (j & 3))) & 0xffu);
+            const uint32_t* prow = (const uint32_t*)(prof + t * pstride + yAligned);
+            int hmUp, fUp;
+            if (s == 0) {
+                hmUp = borderGap(j, open, ext) + scale - c;
+                fUp = kNegInf;
+            } else {
+                // (the row above, fetched one column ahead)
+                const int2 above = aboveNext;
+                aboveNext = bnd[(int64_t)min(j + 1, maxNeed - 1) * kLanes];   // (unconditional: no copy behind the load)
+                hmUp = above.x;
+                fUp = above.y;
+            }
+            int hmDiag = aboveHmPrev;
+            aboveHmPrev = hmUp;
+            int cm = INT32_MIN;
+            uint32_t pD[2] = {0, 0}, pE[2] = {0, 0}, pO[2] = {0, 0}, pF[2] = {0, 0};
+            uint32_t wlo = prow[0], four = 0;
+            // (opaque per column: the eight comparisons below stay scalar compares here instead of eight
+            // lane masks kept - and spilled - across the loop)
+            int groups = rows8 >> 3;
+            asm volatile("" : "+s"(groups));
+#pragma unroll
+            for (int i = 0; i < kLanes; ++i) {
+                if ((i & 7) == 0 && (i >> 3) >= groups) break;  // wave-uniform
+                if ((i & 3) == 0) {
+                    const uint32_t whi = prow[(i >> 2) + 1];
+                    four = __builtin_amdgcn_alignbyte(whi, wlo, shift);
+                    wlo = whi;
+                }
+                const int sc = (int)(int8_t)(four >> (8 * (i & 3)));
+                const int d = hmDiag + sc;
+                const int e = max(E[i], HM[i]);
+                const int fm = max(fUp, hmUp);
+                const int f = fm - ext;
+                const int h = max(d, max(e, f));
+                if (MODE == kPerPairTrace) {
+                    // (four accumulators: two flags chained into one - two bits a row, one dword a step for the
+                    // walk - cost the kernel a third more time than the walk gained)
+                    const int k = i >> 5;
+                    pD[k] = shiftInDiffers(pD[k], h, d);
+                    pE[k] = shiftInDiffers(pE[k], h, e);
+                    pO[k] = shiftInDiffers(pO[k], e, HM[i]);
+                    pF[k] = shiftInDiffers(pF[k], fm, hmUp);
+                } else {
+                    cm = max(cm, h);
+                }
+                const int hm = h - c;
+                hmDiag = HM[i];
+                HM[i] = hm;
+                E[i] = e;
+                hmUp = hm;
+                fUp = f;
+            }
+            if (toNext) bnd[(int64_t)j * kLanes] = make_int2(hmUp, fUp);
+            if (MODE == kPerPairTrace) {
+                uint32_t* at = (uint32_t*)(dcol + (int64_t)j * (kLanes / 2 * kLanes));
+                // (the bits of the rows a half strip really holds sit at the top of its planes)
+                at[0 * kLanes] = ~pD[0] << pad0;
+                at[1 * kLanes] = ~pE[0] << pad0;
+                at[2 * kLanes] = ~pO[0] << pad0;
+                at[3 * kLanes] = ~pF[0] << pad0;
+                if (rows8 > 32) {
+                    at[4 * kLanes] = ~pD[1] << pad1;
+                    at[5 * kLanes] = ~pE[1] << pad1;
+                    at[6 * kLanes] = ~pO[1] << pad1;
+                    at[7 * kLanes] = ~pF[1] << pad1;
+                }
+                const bool mine = j == L - 1 && Q > row0 && Q <= row0 + kLanes;  // the lane's last strip
+                if (__builtin_amdgcn_ballot_w64(mine) != 0) {
+                    int v = 0;
+#pragma unroll
+                    for (int i = 0; i < kLanes; ++i) v = (row0 + i == Q - 1) ? HM[i] : v;
+                    if (mine) best = v + c - scale;
+                }
+            } else {
+                // pad rows and columns are bounded by a valid cell that comes earlier in the column-major
+                // scan (perpair_kernel), so the column's maximum may include them
+                const int top = cm - scale;
+                const bool hit = top > sbest && (!stopOn || top >= stopScore);
+                if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+                    int first = -1;
+                    const int want = cm - c;
+#pragma unroll
+                    for (int i = kLanes - 1; i >= 0; --i)
+                        if (i < rows8) first = HM[i] == want ? i : first;
+                    if (hit) {
+                        sbest = top;
+                        srow = first;
+                        scol = j;
+                    }
+                }
+                const bool more = j + 1 < need && !(stopOn && sbest == stopScore);
+                if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+            }
+        }
+        if (MODE != kPerPairTrace && Q > row0 && scol >= 0) {
+            if (sbest > best || (sbest == best && scol < bcol)) {
+                best = sbest;
+                brow = row0 + srow;
+                bcol = scol;
+            }
+        }
+        if (MODE != kPerPairTrace && stopOn && best == stopScore) need = min(need, bcol + 1);
+    }
+
+    if (active) {
+        int bi = -1, bj = -1;
+        if (Q > 0 && L > 0) {
+            bi = brow;
+            bj = bcol;
+        } else {
+            best = 0;
+            if (Q > 0) best = borderGap(Q - 1, open, ext);
+            if (L > 0) best = borderGap(L - 1, open, ext);
+        }
+        a.score[job.out] = best;
+        if (MODE != kPerPairTrace && a.endI) a.endI[job.out] = bi;
+        if (MODE != kPerPairTrace && a.endJ) a.endJ[job.out] = bj;
+    }
+}
+
 }  // namespace
+
+// LDS of the profile kernel for a query of `queryLength` residues (0: the profile does not apply)
+size_t perPairProfileBytes(int queryLength, int alphabet, int* stride) {
+    const int pstride = (queryLength + kLanes + 8 + 3) & ~3;
+    *stride = pstride;
+    const size_t bytes = (size_t)(alphabet + 1) * pstride + 16;
+    return bytes <= 64 * 1024 ? bytes : 0;
+}
 
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
     const dim3 grid((a.nJobs + kBlock - 1) / kBlock), block(kBlock);
+    if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace)) {
+        const size_t lds = (size_t)(a.alphabet + 1) * a.profileStride + 16;
+        if (mode == kAllCells) hipLaunchKernelGGL((perpair_profile_kernel<kAllCells>), grid, block, lds, stream, a);
+        else hipLaunchKernelGGL((perpair_profile_kernel<kPerPairTrace>), grid, block, lds, stream, a);
+        return hipGetLastError();
+    }
     switch (mode) {
         case kAllCells: hipLaunchKernelGGL((perpair_kernel<kAllCells>), grid, block, 0, stream, a); break;
         case kLastRow: hipLaunchKernelGGL((perpair_kernel<kLastRow>), grid, block, 0, stream, a); break;
