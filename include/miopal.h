@@ -149,6 +149,16 @@ int miopalLastKernelTime(MiopalDb* db, float* ms);
  */
 void miopalLastRouting(int64_t counts[4]);
 
+/*
+ * How the passes BEHIND the score / end pass of the calling thread's most recent OPAL_SEARCH_ALIGNMENT
+ * search ran (diagnostics for tests; no reference counterpart). Bits:
+ *   1  start cells: one lane per pair          2  ... in the query-profile form (perpair_profile_kernel)
+ *   4  directions: one lane per pair           8  ... in the query-profile form
+ *  16  operations copied to the host batch by batch beside the next batch
+ * 0: no such search yet, or one whose traceback batches were built on the host.
+ */
+int miopalLastFullRouting(void);
+
 /* Result-struct form, identical in shape to opalSearchDatabase but against
  * the resident mirror (what the platform plugin calls). */
 int miopalSearchResults(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,

@@ -47,7 +47,7 @@ EXPORTS = [
     "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat", "miopalDbCreateSubset",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
-    "miopalLastRouting", "miopalSearchResults", "miopalReleaseCaches",
+    "miopalLastRouting", "miopalLastFullRouting", "miopalSearchResults", "miopalReleaseCaches",
     # test hooks
     "miopalSelfTest", "miopalTestInjectFault",
 ]
@@ -121,6 +121,8 @@ def lib() -> ctypes.CDLL:
         L.miopalSetProfiling.argtypes = [c_vp, c_int]
         L.miopalReleaseCaches.restype = None
         L.miopalReleaseCaches.argtypes = []
+        L.miopalLastFullRouting.restype = c_int
+        L.miopalLastFullRouting.argtypes = []
         L.miopalLastRouting.restype = None
         L.miopalLastRouting.argtypes = [ctypes.POINTER(ctypes.c_int64)]
         L.miopalLastKernelTime.restype = c_int
@@ -308,6 +310,12 @@ class DeviceDatabase:
         counts = (ctypes.c_int64 * 4)()
         lib().miopalLastRouting(counts)
         return tuple(int(c) for c in counts)
+
+    @staticmethod
+    def last_full_routing() -> int:
+        """Bits describing the start-cell and direction passes of the calling thread's most recent
+        `full` search (include/miopal.h, miopalLastFullRouting)."""
+        return int(lib().miopalLastFullRouting())
 
     def set_profiling(self, enabled: bool) -> None:
         lib().miopalSetProfiling(self._h, 1 if enabled else 0)

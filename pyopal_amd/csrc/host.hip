@@ -39,6 +39,7 @@ namespace {
 
 thread_local std::string g_lastError;
 thread_local int64_t g_lastRouting[4] = {0, 0, 0, 0};  // miopalLastRouting
+thread_local int g_lastFullRouting = 0;                // miopalLastFullRouting
 thread_local int g_fault[3] = {0, 0, 0};               // miopalTestInjectFault: kind, unit, spin cap
 
 int fail(int code, const char* fmt, ...) {
@@ -378,6 +379,8 @@ void miopalLastRouting(int64_t counts[4]) {
     if (!counts) return;
     for (int k = 0; k < 4; ++k) counts[k] = g_lastRouting[k];
 }
+
+int miopalLastFullRouting(void) { return g_lastFullRouting; }
 
 int miopalLastKernelTime(MiopalDb* db, float* ms) {
     if (!db || !ms) return 0;
