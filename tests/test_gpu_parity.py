@@ -427,6 +427,54 @@ def test_segmented_views_every_score(capi, qlen, gaps, matrix):
         db.close()
 
 
+@pytest.mark.parametrize("rich", [False, True])
+@pytest.mark.parametrize("gaps", [(3, 1), (1, 1), (2, 3)])
+def test_segmented_views_alignments_across_long_gaps(capi, rich, gaps):
+    """The windows of a long target overlap by the farthest a positive local alignment can reach:
+    Q + (sum over the query of each residue's best score) / min(open, ext) columns (host_search.inc,
+    `pairsBest`; it was Q max(S) before). Alignments that really use that reach: the two halves of the
+    query, exact copies, with up to hundreds of unrelated residues between them, anywhere in targets
+    of thousands of residues - for a query of ordinary composition and for one of tryptophans and
+    cysteines (sum of best scores close to Q max(S)). Every score, end location and - on a sample - start
+    location against the checker."""
+    rng = np.random.default_rng(11 + gaps[0] + 10 * rich)
+    q = _data.random_protein(rng, 48)
+    if rich:
+        q = rng.choice(_data.encode("WCWWHC"), size=48).astype(np.uint8)
+    half = len(q) // 2
+    seqs = []
+    for gap_columns in list(range(0, 120, 3)) + list(range(120, 640, 13)):
+        length = int(rng.integers(1500, 6000))
+        t = _data.random_protein(rng, length)
+        insert = np.concatenate([q[:half], _data.random_protein(rng, gap_columns), q[half:]])
+        at = int(rng.integers(0, length - len(insert)))
+        t[at:at + len(insert)] = insert
+        seqs.append(t)
+    # short targets around them, so that the long ones are the tail of a packed view
+    seqs += [_data.random_protein(rng, int(n)) for n in rng.integers(20, 400, size=3000)]
+    res, off = _oracle.flatten(seqs)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        end = db.search(q, B62, gaps[0], gaps[1], "end", "sw")
+        assert capi.DeviceDatabase.last_routing()[0] < 64, "long targets should stay in the packed kernel"
+        cpu = _cpu_baseline.CpuDatabase(res, off)
+        want = cpu.search_sw(q, B62, gaps[0], gaps[1], 8)
+        cpu.close()
+        np.testing.assert_array_equal(end["score"], want)
+        sample = np.arange(0, 81)
+        sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in sample])
+        ref = _oracle.search(q, sres, soff, B62, gaps[0], gaps[1], "full", "sw")
+        full = db.search(q, B62, gaps[0], gaps[1], "full", "sw", 0, 81)
+        for key in ("score", "end_q", "end_t", "start_q", "start_t"):
+            np.testing.assert_array_equal(full[key], ref[key], err_msg=key)
+        np.testing.assert_array_equal(end["end_t"][:81], ref["end_t"])
+        # some of these alignments do span the gap: longer than the query
+        spans = ref["end_t"] - ref["start_t"] + 1
+        assert (spans > len(q) + 20).sum() >= 5, spans
+    finally:
+        db.close()
+
+
 @pytest.mark.parametrize("qlen,gaps,matrix", [(53, (3, 1), "B62"), (20, (3, 1), "B62"), (64, (11, 1), "B50"),
                                                 (53, (1, 2), "B62"), (30, (5, 2), "B62"), (53, (3, 0), "B62"),
                                                 (100, (11, 1), "B62")])
