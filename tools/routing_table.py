@@ -28,6 +28,17 @@ if quick:
 DISTS = ("uniform300", "lognormal", "bimodal100_3000")
 ALGOS = ("sw", "nw", "hw", "ov")
 MODES = ("score", "end")
+# (a part of the table: RT_NS=20000,100000 RT_QS=64,150 RT_DISTS=lognormal RT_ALGOS=sw,hw RT_MODES=score)
+if os.environ.get("RT_NS"):
+    NS = [int(x) for x in os.environ["RT_NS"].split(",")]
+if os.environ.get("RT_QS"):
+    QS = [int(x) for x in os.environ["RT_QS"].split(",")]
+if os.environ.get("RT_DISTS"):
+    DISTS = tuple(os.environ["RT_DISTS"].split(","))
+if os.environ.get("RT_ALGOS"):
+    ALGOS = tuple(os.environ["RT_ALGOS"].split(","))
+if os.environ.get("RT_MODES"):
+    MODES = tuple(os.environ["RT_MODES"].split(","))
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
 
 
