@@ -155,6 +155,8 @@ void miopalLastRouting(int64_t counts[4]);
  *   1  start cells: one lane per pair          2  ... in the query-profile form (perpair_profile_kernel)
  *   4  directions: one lane per pair           8  ... in the query-profile form
  *  16  operations copied to the host batch by batch beside the next batch
+ *  32  start cells by persistent wavefronts whose lanes take the next pair when they are done
+ *      (perpair_scan_refill_kernel: queries of one 64-row strip)
  * 0: no such search yet, or one whose traceback batches were built on the host.
  */
 int miopalLastFullRouting(void);

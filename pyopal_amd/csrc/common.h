@@ -169,6 +169,11 @@ struct PerPairArgs {
     int profileStride;
     int reversed;
     int64_t residueCount;     // bytes at `residues` (the profile kernel reads them four at a time, clamped; >= 4)
+    // non-null (with computeUnits): the start-cell scan of a one-strip query by persistent wavefronts whose lanes take
+    // the next job when they are done (perpair_scan_refill_kernel); the counter is zero at launch
+    int* jobCounter;
+    int computeUnits;
+    int refillLanes;          // idle lanes of a wavefront that trigger a refill (set by launchPerPair)
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 // LDS bytes of the profile kernel for this query (0: too long for it), and the stride to pass

@@ -441,11 +441,25 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
                 const int top = cm - scale;
                 const bool hit = top > sbest && (!stopOn || top >= stopScore);
                 if (__builtin_amdgcn_ballot_w64(hit) != 0) {
-                    int first = -1;
+                    // the first row that holds the maximum: the first group of eight rows that does, then its rows -
+                    // only the groups a hit lane points at are looked at (perpair_scan_refill_kernel)
                     const int want = cm - c;
+                    int gstar = -1;
 #pragma unroll
-                    for (int i = kLanes - 1; i >= 0; --i)
-                        if (i < rows8) first = HM[i] == want ? i : first;
+                    for (int g = kLanes / 8 - 1; g >= 0; --g) {
+                        if (8 * g >= rows8) continue;
+                        int m = HM[8 * g];
+#pragma unroll
+                        for (int r = 1; r < 8; ++r) m = max(m, HM[8 * g + r]);
+                        gstar = m == want ? g : gstar;
+                    }
+                    int first = -1;
+#pragma unroll
+                    for (int g = 0; g < kLanes / 8; ++g) {
+                        if (__builtin_amdgcn_ballot_w64(hit && gstar == g) == 0) continue;
+#pragma unroll
+                        for (int r = 7; r >= 0; --r) first = (gstar == g && HM[8 * g + r] == want) ? 8 * g + r : first;
+                    }
                     if (hit) {
                         sbest = top;
                         srow = first;
@@ -482,6 +496,202 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
     }
 }
 
+// ---- the start-cell scan of one-strip queries with lanes that take the next pair when they are done ------
+// perpair_profile_kernel<kAllCells> runs a wavefront until its longest lane is done: the reversed-prefix scans of
+// cfg3 (53-aa query, gap 3/1) need 60 columns on average and 95 for the longest of 64 - a third of the lane
+// columns idle. Here a wavefront is persistent: every fourth column it counts the lanes that have met their
+// optimum, and once kRefillLanes of them are idle they take the next pairs of the list (one atomic per
+// wavefront and refill), start over at column 0 of their own pair and run beside the lanes still at work. A lane's
+// column is its own (border, scale and target position follow it); refills happen on multiples of four columns,
+// so the four-residue loads stay in step. Same cell, same candidates, same results as the kernel above.
+constexpr int kRefillLanes = 12;
+
+__global__ __launch_bounds__(kBlock) void perpair_scan_refill_kernel(PerPairArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int8_t prof[];
+    const int A = a.alphabet;
+    const int Qtot = a.queryLength;   // <= 64: one strip
+    const int pstride = a.profileStride;
+    for (int idx = threadIdx.x; idx < (A + 1) * pstride; idx += kBlock) {
+        const int t = idx / pstride, y = idx - t * pstride;
+        int v = kProfilePad;
+        if (t < A && y < Qtot) v = a.matrix[(int)a.query[a.reversed ? Qtot - 1 - y : y] * A + t] + a.gapOpen;
+        prof[idx] = (int8_t)v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int open = a.gapOpen, ext = a.gapExt, c = open - ext;
+    const int rows8 = (min(Qtot, kLanes) + 7) & ~7;
+    const uint32_t padWord = (uint32_t)A * 0x01010101u;
+    const uint8_t* const dbLo = a.residues;
+    const uint8_t* const dbHi = a.residues + a.residueCount - 4;
+
+    // the lane's pair
+    bool busy = false;
+    int Q = 0, L = 0, out = 0, stopScore = 0;
+    bool stopOn = false;
+    const uint8_t* tptr = a.residues;
+    int yAligned = Qtot & ~3;
+    uint32_t shift = (uint32_t)Qtot & 3u;
+    int j = 0, scale = 0;
+    int HM[kLanes], E[kLanes];
+#pragma unroll
+    for (int i = 0; i < kLanes; ++i) HM[i] = E[i] = kNegInf;
+    int aboveHmPrev = -open;
+    int sbest = INT32_MIN, srow = -1, scol = -1;
+    uint32_t wcur = padWord, rawNext = padWord;
+    bool exhausted = false;   // wave-uniform: no pair left to take
+
+    auto wanted = [&](int j0) { return a.reversed ? tptr - j0 - 3 : tptr + j0; };
+    auto fetchRaw = [&](int j0) -> uint32_t {
+        const uint8_t* at = wanted(j0);
+        at = at < dbLo ? dbLo : at;
+        at = at > dbHi ? dbHi : at;
+        uint32_t w;
+        __builtin_memcpy(&w, at, 4);
+        return w;
+    };
+    auto inPlace = [&](uint32_t raw, int j0) -> uint32_t {
+        const uint8_t* at = wanted(j0);
+        const int64_t below = dbLo - at, above = at - dbHi;
+        uint32_t w = raw;
+        if (below > 0) w = below >= 4 ? 0u : raw << (8 * (int)below);
+        if (above > 0) w = above >= 4 ? 0u : raw >> (8 * (int)above);
+        if (a.reversed) w = __builtin_bswap32(w);
+        const int valid = L - j0;
+        const uint32_t keep = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : (1u << (8 * valid)) - 1u;
+        return (w & keep) | (padWord & ~keep);
+    };
+
+    for (int w = 0;; ++w) {
+        if ((w & 3) == 0) {
+            const uint64_t idleMask = __builtin_amdgcn_ballot_w64(!busy);
+            const int idle = __builtin_popcountll(idleMask);
+            if (exhausted && idle == kLanes) break;
+            if (!exhausted && (idle >= a.refillLanes || w == 0)) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(a.jobCounter, idle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + idle >= a.nJobs) exhausted = true;
+                if (!busy) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0));
+                    const int k = base + rank;
+                    if (k < a.nJobs) {
+                        const PairJob job = a.jobs[k];
+                        Q = job.qLen;
+                        L = job.tLen;
+                        out = job.out;
+                        stopOn = (job.rules & kRuleStop) != 0;
+                        stopScore = job.stop;
+                        tptr = a.residues + job.tOff;
+                        const int ys = min(a.reversed ? Qtot - 1 - job.qOff : job.qOff, Qtot);
+                        shift = (uint32_t)ys & 3u;
+                        yAligned = ys & ~3;
+                        j = 0;
+                        scale = 0;
+                        sbest = INT32_MIN;
+                        srow = scol = -1;
+                        aboveHmPrev = -open;
+#pragma unroll
+                        for (int i = 0; i < kLanes; ++i) {
+                            HM[i] = i < Q ? borderGap(i, open, ext) - open : kNegInf;
+                            E[i] = kNegInf;
+                        }
+                        rawNext = fetchRaw(0);
+                        busy = Q > 0 && L > 0;
+                        if (!busy) {
+                            // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+                            int v = 0;
+                            if (Q > 0) v = borderGap(Q - 1, open, ext);
+                            if (L > 0) v = borderGap(L - 1, open, ext);
+                            a.score[out] = v;
+                            if (a.endI) a.endI[out] = -1;
+                            if (a.endJ) a.endJ[out] = -1;
+                        }
+                    }
+                }
+                if (exhausted && __builtin_amdgcn_ballot_w64(busy) == 0) break;
+            }
+            wcur = inPlace(rawNext, j);
+            rawNext = fetchRaw(j + 4);
+        }
+        const int t = (int)((wcur >> (8 * (w & 3))) & 0xffu);
+        const uint32_t* prow = (const uint32_t*)(prof + t * pstride + yAligned);
+        int hmUp = borderGap(j, open, ext) + scale - c;
+        int fUp = kNegInf;
+        int hmDiag = aboveHmPrev;
+        aboveHmPrev = hmUp;
+        int cm = INT32_MIN;
+        uint32_t wlo = prow[0], four = 0;
+        int groups = rows8 >> 3;
+        asm volatile("" : "+s"(groups));
+#pragma unroll
+        for (int i = 0; i < kLanes; ++i) {
+            if ((i & 7) == 0 && (i >> 3) >= groups) break;  // wave-uniform
+            if ((i & 3) == 0) {
+                const uint32_t whi = prow[(i >> 2) + 1];
+                four = __builtin_amdgcn_alignbyte(whi, wlo, shift);
+                wlo = whi;
+            }
+            const int sc = (int)(int8_t)(four >> (8 * (i & 3)));
+            const int d = hmDiag + sc;
+            const int e = max(E[i], HM[i]);
+            const int fm = max(fUp, hmUp);
+            const int f = fm - ext;
+            const int h = max(d, max(e, f));
+            cm = max(cm, h);
+            const int hm = h - c;
+            hmDiag = HM[i];
+            HM[i] = hm;
+            E[i] = e;
+            hmUp = hm;
+            fUp = f;
+        }
+        const int top = cm - scale;
+        const bool hit = busy && top > sbest && (!stopOn || top >= stopScore);
+        if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+            // the first row that holds the maximum: the first group of eight rows that does (their maxima are taken
+            // here, from the column just written - kept across the column they cost 50 registers and a wavefront per
+            // SIMD), then its rows - only the groups a hit lane points at are looked at (comparing all 64 rows was a
+            // quarter of this kernel's instructions)
+            const int want = cm - c;
+            int gstar = -1;
+#pragma unroll
+            for (int g = kLanes / 8 - 1; g >= 0; --g) {
+                if (8 * g >= rows8) continue;
+                int m = HM[8 * g];
+#pragma unroll
+                for (int r = 1; r < 8; ++r) m = max(m, HM[8 * g + r]);
+                gstar = m == want ? g : gstar;
+            }
+            int first = -1;
+#pragma unroll
+            for (int g = 0; g < kLanes / 8; ++g) {
+                if (__builtin_amdgcn_ballot_w64(hit && gstar == g) == 0) continue;
+#pragma unroll
+                for (int r = 7; r >= 0; --r) first = (gstar == g && HM[8 * g + r] == want) ? 8 * g + r : first;
+            }
+            if (hit) {
+                sbest = top;
+                srow = first;
+                scol = j;
+            }
+        }
+        const bool more = j + 1 < L && !(stopOn && sbest == stopScore);
+        const bool done = busy && !more;
+        if (__builtin_amdgcn_ballot_w64(done) != 0) {
+            if (done) {
+                a.score[out] = sbest;
+                if (a.endI) a.endI[out] = scol >= 0 ? srow : -1;
+                if (a.endJ) a.endJ[out] = scol;
+                busy = false;
+            }
+        }
+        ++j;
+        scale += ext;
+    }
+}
+
 }  // namespace
 
 // LDS of the profile kernel for a query of `queryLength` residues (0: the profile does not apply)
@@ -497,6 +707,17 @@ hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
     const dim3 grid((a.nJobs + kBlock - 1) / kBlock), block(kBlock);
     if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace)) {
         const size_t lds = (size_t)(a.alphabet + 1) * a.profileStride + 16;
+        if (mode == kAllCells && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
+            // persistent wavefronts, three per SIMD (165 VGPRs)
+            int perCu = 3;
+            if (const char* e = getenv("MIOPAL_SCAN_BLOCKS_PER_CU")) perCu = std::max(1, atoi(e));   // (experiments)
+            PerPairArgs b = a;
+            b.refillLanes = kRefillLanes;
+            if (const char* e = getenv("MIOPAL_SCAN_REFILL_LANES")) b.refillLanes = std::min(64, std::max(1, atoi(e)));
+            const int blocks = (int)std::min<int64_t>(((int64_t)a.nJobs + kBlock - 1) / kBlock, (int64_t)a.computeUnits * perCu);
+            hipLaunchKernelGGL(perpair_scan_refill_kernel, dim3(blocks), block, lds, stream, b);
+            return hipGetLastError();
+        }
         if (mode == kAllCells) hipLaunchKernelGGL((perpair_profile_kernel<kAllCells>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((perpair_profile_kernel<kPerPairTrace>), grid, block, lds, stream, a);
         return hipGetLastError();

@@ -50,10 +50,33 @@ def both_forms(capi, monkeypatch, q, res, off, matrix, go, ge, algo="sw", expect
     finally:
         db.close()
     if expect_profile and off[-1] >= 4:
-        # directions always; start cells when the region is "all cells" (Smith-Waterman)
+        # directions always; start cells when the region is "all cells" (Smith-Waterman): queries of one strip by
+        # the persistent wavefronts that refill their lanes
         assert routing & 12 == 12, routing
         assert (routing & 3 == 3) == (algo == "sw"), routing
+        assert bool(routing & 32) == (algo == "sw" and len(q) <= 64), routing
     return new, old
+
+
+@pytest.mark.parametrize("qlen", [1, 8, 33, 53, 64])
+def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen):
+    # the start-cell scan of a one-strip query on the kernel that longer queries use (a wavefront lasts as long as
+    # its longest lane), against the persistent one and the checker
+    rng = np.random.default_rng(500 + qlen)
+    res, off = _data.random_db(rng, rng.integers(1, 400, size=5000))
+    q = _data.random_protein(rng, qlen)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        refill = db.search(q, B62, 3, 1, "full", "sw")
+        assert capi.DeviceDatabase.last_full_routing() & 32
+        monkeypatch.setenv("MIOPAL_NO_SCAN_REFILL", "1")
+        plain = db.search(q, B62, 3, 1, "full", "sw")
+        assert capi.DeviceDatabase.last_full_routing() & 35 == 3
+    finally:
+        db.close()
+    ref = _oracle.search(q, res, off, B62, 3, 1, "full", "sw")
+    compare(refill, ref, "full", f"refill Q={qlen}")
+    compare(plain, ref, "full", f"no refill Q={qlen}")
 
 
 @pytest.mark.parametrize("qlen", [1, 5, 8, 9, 31, 32, 33, 53, 63, 64, 65, 96, 97, 128, 150, 300])

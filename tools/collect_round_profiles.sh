@@ -12,10 +12,11 @@ bash $root/tools/collect_pmc.sh $tag q150_sw interseq_pair_strips_kernel q150_10
 bash $root/tools/collect_pmc.sh $tag q300_sw interseq_pair_strips_kernel q300_1000000x300 sw score 5
 bash $root/tools/collect_pmc.sh $tag q53_nw interseq_pair_global_kernel q53_1000000x300 nw score 5
 # the passes behind the end pass of a `full` search: start-cell scan (<3> = region "all cells"), directions (<4>), walk
-for w in cfg3full:q53_1000000x300 q300full:q300_1000000x300; do
-    name=${w%%:*}
-    bash $root/tools/collect_pmc.sh $tag $name "perpair_profile_kernel<3>,perpair_profile_kernel<4>,walk_kernel" ${w##*:} sw full 3
-    mv "$root/gpurun_out/${tag}_pmc_${name}_perpair_profile_kernel<3>.json" $root/gpurun_out/${tag}_pmc_${name}_scan.json
+# (one-strip queries: the scan is perpair_scan_refill_kernel)
+for w in cfg3full:q53_1000000x300:perpair_scan_refill_kernel "q300full:q300_1000000x300:perpair_profile_kernel<3>"; do
+    name=${w%%:*}; rest=${w#*:}; scan=${rest#*:}; workload=${rest%%:*}
+    bash $root/tools/collect_pmc.sh $tag $name "$scan,perpair_profile_kernel<4>,walk_kernel" $workload sw full 3
+    mv "$root/gpurun_out/${tag}_pmc_${name}_${scan}.json" $root/gpurun_out/${tag}_pmc_${name}_scan.json
     mv "$root/gpurun_out/${tag}_pmc_${name}_perpair_profile_kernel<4>.json" $root/gpurun_out/${tag}_pmc_${name}_directions.json
     mv $root/gpurun_out/${tag}_pmc_${name}_walk_kernel.json $root/gpurun_out/${tag}_pmc_${name}_walk.json
 done
