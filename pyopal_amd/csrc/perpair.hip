@@ -1,5 +1,11 @@
-// Lane-per-pair kernel for gfx950: the second and third pass of a `full` search
-// (src/pyopal/opal.pxd:17-19, OPAL_SEARCH_ALIGNMENT) for queries of one 64-row strip.
+// Lane-per-pair kernels for gfx950: the second and third pass of a `full` search
+// (src/pyopal/opal.pxd:17-19, OPAL_SEARCH_ALIGNMENT). Three kernels, same model, same results:
+//   perpair_kernel<MODE>           matrix rows in LDS; every region of the start-cell scan, any matrix / gaps
+//   perpair_profile_kernel<MODE>   query profile in LDS, columns on a sliding scale, bit planes (round 3): the
+//                                  Smith-Waterman scan and the directions of every mode when score + open fits a byte
+//   perpair_scan_refill_kernel     the Smith-Waterman scan of a one-strip query by persistent wavefronts whose
+//                                  lanes take the next pair when they are done
+// The first one is described here, the others where they start.
 //
 // After the score/end pass every target has its own small problem anchored on its end cell:
 // the reversed prefixes q[endQ..0] x t[endT..0] (start-location scan) and then the rectangle
@@ -708,7 +714,7 @@ hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
     if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace)) {
         const size_t lds = (size_t)(a.alphabet + 1) * a.profileStride + 16;
         if (mode == kAllCells && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
-            // persistent wavefronts, three per SIMD (165 VGPRs)
+            // persistent wavefronts, three per SIMD (163 VGPRs)
             int perCu = 3;
             if (const char* e = getenv("MIOPAL_SCAN_BLOCKS_PER_CU")) perCu = std::max(1, atoi(e));   // (experiments)
             PerPairArgs b = a;

@@ -72,20 +72,26 @@ def test_reference_vectors_small_search_routing(capi, vec, mode, small_search_ro
 def test_small_searches_of_longer_queries(capi, small_search_routing, qlen):
     """Production routing of small searches (host_search.inc, kSmallSteps): a few targets against a query of
     several strips stay on the wavefront-per-pair kernel (shorter start-up than the packed kernels' views and
-    tables) as long as their strips x anti-diagonal steps are few; more targets take the packed kernels."""
+    tables) while an estimate of its time stays below one of theirs; more targets, or long ones, take the packed
+    kernels."""
     rng = np.random.default_rng(300 + qlen)
     q = _data.random_protein(rng, qlen)
     for n, lengths_hi in ((1, 400), (7, 400), (300, 300)):
-        res, off = _data.random_db(rng, rng.integers(1, lengths_hi, size=n))
+        lengths = rng.integers(1, lengths_hi, size=n)
+        res, off = _data.random_db(rng, lengths)
         strips = -(-qlen // 64)
         steps = strips * (int(off[-1]) + 63 * n)
+        # (the host's estimate, host_search.inc)
+        per_pair = 0.075 + max(steps / 7e6, (int(lengths.max()) + 64 * strips) * 0.00025)
+        expect_small = per_pair < 0.26 + 0.0006 * qlen
         for algo in ALGOS:
             for mode in ("score", "end", "full"):
                 gpu, ref = run_both(capi, q, res, off, B62, 3, 1, mode, algo)
                 compare(gpu, ref, mode, f"{algo}/{mode} Q={qlen} n={n}")
                 if mode == "score":
                     routed = capi.DeviceDatabase.last_routing()
-                    assert (routed[0] == n) == (steps <= 2_500_000), (routed, steps)
+                    assert (routed[0] == n) == expect_small, (routed, steps, per_pair)
+        assert expect_small or n == 300, "the handful of targets is what the routing is for"
     # beyond the bound: the packed kernels
     res, off = _data.random_db(rng, np.full(20_000, 300))
     gpu, ref = run_both(capi, q, res, off, B62, 3, 1, "score", "sw")
