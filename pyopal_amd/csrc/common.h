@@ -163,7 +163,7 @@ struct PerPairArgs {
     int64_t boundaryStride;   // columns per 64 consecutive jobs (>= longest target window)
     const int* skipWaves;     // hybrid direction pass: the first *skipWaves wavefronts' jobs belong to
                               // intraseq_kernel (null: none)
-    // > 0: perpair_profile_kernel (regions kAllCells and kPerPairTrace only): bytes per residue row of its
+    // > 0: perpair_profile_kernel (every region of the scan but kLastCell, and kPerPairTrace): bytes per residue row of its
     // query profile in LDS (perPairProfileBytes); every job walks the query the same way (`reversed`), and
     // the directions leave as bit planes: [job / 64][strip][j][rows 0-31 | 32-63][plane][job % 64] dwords
     int profileStride;

@@ -2,7 +2,7 @@
 // (src/pyopal/opal.pxd:17-19, OPAL_SEARCH_ALIGNMENT). Three kernels, same model, same results:
 //   perpair_kernel<MODE>           matrix rows in LDS; every region of the start-cell scan, any matrix / gaps
 //   perpair_profile_kernel<MODE>   query profile in LDS, columns on a sliding scale, bit planes (round 3): the
-//                                  Smith-Waterman scan and the directions of every mode when score + open fits a byte
+//                                  scans and the directions of every mode when score + open fits a byte
 //   perpair_scan_refill_kernel     the Smith-Waterman scan of a one-strip query by persistent wavefronts whose
 //                                  lanes take the next pair when they are done
 // The first one is described here, the others where they start.
@@ -255,7 +255,12 @@ __device__ __forceinline__ uint32_t shiftInDiffers(uint32_t plane, int larger, i
     return __builtin_amdgcn_alignbit(plane, (uint32_t)(part - larger), 31);
 }
 
-template <int MODE>  // kAllCells (start-cell scan) or kPerPairTrace (directions)
+__device__ __forceinline__ int pick2(bool second, int a, int b) {
+    asm volatile("" : "+v"(a), "+v"(b));
+    return second ? b : a;
+}
+
+template <int MODE>  // kAllCells / kLastRow / kLastRowCol (start-cell scan) or kPerPairTrace (directions)
 __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) int8_t prof[];
     const int A = a.alphabet;
@@ -316,6 +321,11 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
             E[i] = kNegInf;
         }
         int sbest = INT32_MIN, srow = -1, scol = -1;
+        // regions "last row" / "last row or column" (HW / OV): the candidates of a column are one row of the lane's
+        // own - picked out of the 64 registers by the bits of its index, 63 selects a column - and, in the lane's
+        // last column, every row of its window
+        const int lastLocal = Q - 1 - row0;
+        const bool lastHere = lastLocal >= 0 && lastLocal < kLanes;
         uint8_t* dcol = MODE == kPerPairTrace ? dirs + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes) : nullptr;
         int aboveHmPrev = (s == 0 ? 0 : borderGap(row0 - 1, open, ext)) - open;
         // bits of the rows a half strip really holds sit at the top of its planes
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
                     pE[k] = shiftInDiffers(pE[k], h, e);
                     pO[k] = shiftInDiffers(pO[k], e, HM[i]);
                     pF[k] = shiftInDiffers(pF[k], fm, hmUp);
-                } else {
+                } else if (MODE != kLastRow) {
                     cm = max(cm, h);
                 }
                 const int hm = h - c;
@@ -444,8 +454,38 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
             } else {
                 // pad rows and columns are bounded by a valid cell that comes earlier in the column-major
                 // scan (perpair_kernel), so the column's maximum may include them
-                const int top = cm - scale;
-                const bool hit = top > sbest && (!stopOn || top >= stopScore);
+                int top = MODE == kLastRow ? INT32_MIN : cm - scale;   // ("last row" keeps no column maximum)
+                bool hit = top > sbest && (!stopOn || top >= stopScore);
+                if (MODE == kLastRow || MODE == kLastRowCol) {
+                    // H of the lane's last query row in this column
+                    // (every level spelled out: a loop over the levels left the array in scratch memory)
+                    const bool b0 = lastLocal & 1, b1 = lastLocal & 2, b2 = lastLocal & 4, b3 = lastLocal & 8,
+                               b4 = lastLocal & 16, b5 = lastLocal & 32;
+                    int p32[32], p16[16], p8[8], p4[4], p2[2];
+                    // (pick2 hides the operands: "one of two neighbouring array elements" otherwise becomes a load at a
+                    // computed address, and the 64 registers an array in scratch memory)
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) p32[k] = pick2(b0, HM[2 * k], HM[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) p16[k] = pick2(b1, p32[2 * k], p32[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p8[k] = pick2(b2, p16[2 * k], p16[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) p4[k] = pick2(b3, p8[2 * k], p8[2 * k + 1]);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) p2[k] = pick2(b4, p4[2 * k], p4[2 * k + 1]);
+                    const int topLast = pick2(b5, p2[0], p2[1]) + c - scale;
+                    const bool lastRowHit = lastHere && j < L && topLast > sbest && (!stopOn || topLast >= stopScore);
+                    // the lane's last column: every row of its window is a candidate, in row order - the column's first
+                    // maximum (rows beyond the window stay below the one above them); elsewhere the last row alone
+                    const bool wholeColumn = MODE == kLastRowCol && j == L - 1 && row0 < Q;
+                    hit = wholeColumn && hit;
+                    if (lastRowHit && !hit) {
+                        sbest = topLast;
+                        srow = lastLocal;
+                        scol = j;
+                    }
+                }
                 if (__builtin_amdgcn_ballot_w64(hit) != 0) {
                     // the first row that holds the maximum: the first group of eight rows that does, then its rows -
                     // only the groups a hit lane points at are looked at (perpair_scan_refill_kernel)
@@ -711,7 +751,7 @@ size_t perPairProfileBytes(int queryLength, int alphabet, int* stride) {
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
     const dim3 grid((a.nJobs + kBlock - 1) / kBlock), block(kBlock);
-    if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace)) {
+    if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace || mode == kLastRow || mode == kLastRowCol)) {
         const size_t lds = (size_t)(a.alphabet + 1) * a.profileStride + 16;
         if (mode == kAllCells && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
             // persistent wavefronts, three per SIMD (163 VGPRs)
@@ -725,6 +765,8 @@ hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
             return hipGetLastError();
         }
         if (mode == kAllCells) hipLaunchKernelGGL((perpair_profile_kernel<kAllCells>), grid, block, lds, stream, a);
+        else if (mode == kLastRow) hipLaunchKernelGGL((perpair_profile_kernel<kLastRow>), grid, block, lds, stream, a);
+        else if (mode == kLastRowCol) hipLaunchKernelGGL((perpair_profile_kernel<kLastRowCol>), grid, block, lds, stream, a);
         else hipLaunchKernelGGL((perpair_profile_kernel<kPerPairTrace>), grid, block, lds, stream, a);
         return hipGetLastError();
     }

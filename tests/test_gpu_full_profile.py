@@ -50,10 +50,10 @@ def both_forms(capi, monkeypatch, q, res, off, matrix, go, ge, algo="sw", expect
     finally:
         db.close()
     if expect_profile and off[-1] >= 4:
-        # directions always; start cells when the region is "all cells" (Smith-Waterman): queries of one strip by
-        # the persistent wavefronts that refill their lanes
+        # directions always; start cells of every mode that has a scan (NW starts at the origin); Smith-Waterman
+        # queries of one strip by the persistent wavefronts that refill their lanes
         assert routing & 12 == 12, routing
-        assert (routing & 3 == 3) == (algo == "sw"), routing
+        assert (routing & 3 == 3) == (algo != "nw"), routing
         assert bool(routing & 32) == (algo == "sw" and len(q) <= 64), routing
     return new, old
 
@@ -93,12 +93,12 @@ def test_against_the_checker(capi, lane_per_pair, monkeypatch, qlen, gaps):
 
 
 @pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
-def test_other_modes_take_the_profile_form_for_their_directions(capi, lane_per_pair, monkeypatch, algo):
-    # (their start cells are scanned by the kernel of before - regions "last row" / "last row or column";
-    # the direction pass is shared)
+def test_other_modes_take_the_profile_form_too(capi, lane_per_pair, monkeypatch, algo):
+    # HW / OV: start cells in the regions "last row" / "last row or column" (the lane's last query row picked out of
+    # the 64 registers every column; the whole last column for OV); NW: no scan; the direction pass is shared
     rng = np.random.default_rng(77)
     res, off = _data.random_db(rng, rng.integers(1, 300, size=500))
-    for qlen in (20, 64, 130):
+    for qlen in (1, 20, 63, 64, 65, 130, 200):
         q = _data.random_protein(rng, qlen)
         new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1, algo)
         ref = _oracle.search(q, res, off, B62, 3, 1, "full", algo)
@@ -179,6 +179,27 @@ def test_scores_beyond_the_byte_leave_the_form(capi, lane_per_pair, monkeypatch)
             db.close()
         ref = _oracle.search(q, res, off, matrix, go, ge, "full", "sw")
         compare(got, ref, "full", f"gaps {go}/{ge}")
+
+
+@pytest.mark.parametrize("algo", ["hw", "ov"])
+def test_many_pairs_of_the_other_modes(capi, monkeypatch, algo):
+    # the regions "last row" / "last row or column" at a size where the host picks one lane per pair by itself:
+    # every alignment against the kernels of before, a sample against the checker
+    rng = np.random.default_rng(41)
+    lengths = np.clip(rng.lognormal(mean=5.0, sigma=0.5, size=120_000), 10, 1500).astype(np.int64)
+    res, off = _data.random_db(rng, lengths)
+    for qlen in (53, 150):
+        q = _data.random_protein(rng, qlen)
+        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1, algo)
+        for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
+            np.testing.assert_array_equal(new[key], old[key], err_msg=f"{key} {algo} Q={qlen}")
+        pick = np.sort(rng.choice(len(lengths), size=200, replace=False))
+        sub_res = np.concatenate([res[off[k]:off[k + 1]] for k in pick])
+        sub_off = np.concatenate([[0], np.cumsum(lengths[pick])]).astype(np.int64)
+        ref = _oracle.search(q, sub_res, sub_off, B62, 3, 1, "full", algo)
+        for x, k in enumerate(pick):
+            assert new["score"][k] == ref["score"][x]
+            assert new["aln"][k].tolist() == ref["aln"][x].tolist(), f"alignment of target {k} {algo} Q={qlen}"
 
 
 def test_many_pairs_in_batches(capi, monkeypatch):
