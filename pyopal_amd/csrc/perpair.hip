@@ -552,6 +552,7 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
 // so the four-residue loads stay in step. Same cell, same candidates, same results as the kernel above.
 constexpr int kRefillLanes = 12;
 
+template <int MODE>  // kAllCells, kLastRow or kLastRowCol
 __global__ __launch_bounds__(kBlock) void perpair_scan_refill_kernel(PerPairArgs a) {
     extern __shared__ __attribute__((aligned(16))) int8_t prof[];
     const int A = a.alphabet;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void perpair_scan_refill_kernel(PerPairArgs
             const int fm = max(fUp, hmUp);
             const int f = fm - ext;
             const int h = max(d, max(e, f));
-            cm = max(cm, h);
+            if (MODE != kLastRow) cm = max(cm, h);
             const int hm = h - c;
             hmDiag = HM[i];
             HM[i] = hm;
@@ -693,8 +694,34 @@ __global__ __launch_bounds__(kBlock) void perpair_scan_refill_kernel(PerPairArgs
             hmUp = hm;
             fUp = f;
         }
-        const int top = cm - scale;
-        const bool hit = busy && top > sbest && (!stopOn || top >= stopScore);
+        const int top = MODE == kLastRow ? INT32_MIN : cm - scale;
+        bool hit = busy && top > sbest && (!stopOn || top >= stopScore);
+        if (MODE == kLastRow || MODE == kLastRowCol) {
+            // HW / OV: the lane's last query row (perpair_profile_kernel), every row in its last column
+            const int lastLocal = Q - 1;
+            const bool b0 = lastLocal & 1, b1 = lastLocal & 2, b2 = lastLocal & 4, b3 = lastLocal & 8,
+                       b4 = lastLocal & 16, b5 = lastLocal & 32;
+            int p32[32], p16[16], p8[8], p4[4], p2[2];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) p32[k] = pick2(b0, HM[2 * k], HM[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) p16[k] = pick2(b1, p32[2 * k], p32[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p8[k] = pick2(b2, p16[2 * k], p16[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p4[k] = pick2(b3, p8[2 * k], p8[2 * k + 1]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) p2[k] = pick2(b4, p4[2 * k], p4[2 * k + 1]);
+            const int topLast = pick2(b5, p2[0], p2[1]) + c - scale;
+            const bool lastRowHit = busy && j < L && topLast > sbest && (!stopOn || topLast >= stopScore);
+            const bool wholeColumn = MODE == kLastRowCol && j == L - 1;
+            hit = wholeColumn && hit;
+            if (lastRowHit && !hit) {
+                sbest = topLast;
+                srow = lastLocal;
+                scol = j;
+            }
+        }
         if (__builtin_amdgcn_ballot_w64(hit) != 0) {
             // the first row that holds the maximum: the first group of eight rows that does (their maxima are taken
             // here, from the column just written - kept across the column they cost 50 registers and a wavefront per
@@ -753,15 +780,17 @@ hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
     const dim3 grid((a.nJobs + kBlock - 1) / kBlock), block(kBlock);
     if (a.profileStride > 0 && (mode == kAllCells || mode == kPerPairTrace || mode == kLastRow || mode == kLastRowCol)) {
         const size_t lds = (size_t)(a.alphabet + 1) * a.profileStride + 16;
-        if (mode == kAllCells && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
-            // persistent wavefronts, three per SIMD (163 VGPRs)
-            int perCu = 3;
+        if (mode != kPerPairTrace && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
+            // persistent wavefronts, three per SIMD (163 VGPRs; the HW / OV regions' row select takes 190: two)
+            int perCu = mode == kAllCells ? 3 : 2;
             if (const char* e = getenv("MIOPAL_SCAN_BLOCKS_PER_CU")) perCu = std::max(1, atoi(e));   // (experiments)
             PerPairArgs b = a;
             b.refillLanes = kRefillLanes;
             if (const char* e = getenv("MIOPAL_SCAN_REFILL_LANES")) b.refillLanes = std::min(64, std::max(1, atoi(e)));
             const int blocks = (int)std::min<int64_t>(((int64_t)a.nJobs + kBlock - 1) / kBlock, (int64_t)a.computeUnits * perCu);
-            hipLaunchKernelGGL(perpair_scan_refill_kernel, dim3(blocks), block, lds, stream, b);
+            if (mode == kAllCells) hipLaunchKernelGGL(perpair_scan_refill_kernel<kAllCells>, dim3(blocks), block, lds, stream, b);
+            else if (mode == kLastRow) hipLaunchKernelGGL(perpair_scan_refill_kernel<kLastRow>, dim3(blocks), block, lds, stream, b);
+            else hipLaunchKernelGGL(perpair_scan_refill_kernel<kLastRowCol>, dim3(blocks), block, lds, stream, b);
             return hipGetLastError();
         }
         if (mode == kAllCells) hipLaunchKernelGGL((perpair_profile_kernel<kAllCells>), grid, block, lds, stream, a);

@@ -50,16 +50,17 @@ def both_forms(capi, monkeypatch, q, res, off, matrix, go, ge, algo="sw", expect
     finally:
         db.close()
     if expect_profile and off[-1] >= 4:
-        # directions always; start cells of every mode that has a scan (NW starts at the origin); Smith-Waterman
-        # queries of one strip by the persistent wavefronts that refill their lanes
+        # directions always; start cells of every mode that has a scan (NW starts at the origin); queries of one
+        # strip by the persistent wavefronts that refill their lanes
         assert routing & 12 == 12, routing
         assert (routing & 3 == 3) == (algo != "nw"), routing
-        assert bool(routing & 32) == (algo == "sw" and len(q) <= 64), routing
+        assert bool(routing & 32) == (algo != "nw" and len(q) <= 64), routing
     return new, old
 
 
+@pytest.mark.parametrize("algo", ["sw", "hw", "ov"])
 @pytest.mark.parametrize("qlen", [1, 8, 33, 53, 64])
-def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen):
+def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen, algo):
     # the start-cell scan of a one-strip query on the kernel that longer queries use (a wavefront lasts as long as
     # its longest lane), against the persistent one and the checker
     rng = np.random.default_rng(500 + qlen)
@@ -67,16 +68,16 @@ def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen):
     q = _data.random_protein(rng, qlen)
     db = capi.DeviceDatabase(res, off, 24)
     try:
-        refill = db.search(q, B62, 3, 1, "full", "sw")
+        refill = db.search(q, B62, 3, 1, "full", algo)
         assert capi.DeviceDatabase.last_full_routing() & 32
         monkeypatch.setenv("MIOPAL_NO_SCAN_REFILL", "1")
-        plain = db.search(q, B62, 3, 1, "full", "sw")
+        plain = db.search(q, B62, 3, 1, "full", algo)
         assert capi.DeviceDatabase.last_full_routing() & 35 == 3
     finally:
         db.close()
-    ref = _oracle.search(q, res, off, B62, 3, 1, "full", "sw")
-    compare(refill, ref, "full", f"refill Q={qlen}")
-    compare(plain, ref, "full", f"no refill Q={qlen}")
+    ref = _oracle.search(q, res, off, B62, 3, 1, "full", algo)
+    compare(refill, ref, "full", f"refill {algo} Q={qlen}")
+    compare(plain, ref, "full", f"no refill {algo} Q={qlen}")
 
 
 @pytest.mark.parametrize("qlen", [1, 5, 8, 9, 31, 32, 33, 53, 63, 64, 65, 96, 97, 128, 150, 300])
