@@ -249,10 +249,15 @@ class DeviceDatabase:
     def search(self, query: np.ndarray, matrix: np.ndarray, gap_open: int = 3, gap_extend: int = 1,
                mode: str = "score", algorithm: str = "sw", start: int = 0,
                end: typing.Optional[int] = None,
-               score_out: typing.Optional[np.ndarray] = None) -> typing.Dict[str, typing.Any]:
+               score_out: typing.Optional[np.ndarray] = None,
+               reuse: typing.Optional[typing.Dict[str, typing.Any]] = None) -> typing.Dict[str, typing.Any]:
         """miopalSearch with numpy outputs (same keys as tests/_oracle.search). ``score_out``: an
         int32 array of end - start entries to receive the scores (a caller that re-uses its result
-        array; when it is pinned, device-visible host memory the kernel writes into it directly)."""
+        array; when it is pinned, device-visible host memory the kernel writes into it directly).
+        ``reuse``: the result of an earlier search of the same slice and search type whose per-target
+        arrays (scores, locations, operation offsets) are written again instead of fresh ones - the
+        earlier result's arrays then hold the new values (a million targets: 36 MB of pages that need
+        not be faulted in again, 1.3 ms of a 11.5-ms `full` search)."""
         end = self.count if end is None else min(end, self.count)
         n = max(end - start, 0)
         q = np.ascontiguousarray(query, dtype=np.uint8)
@@ -262,16 +267,25 @@ class DeviceDatabase:
                                       not score_out.flags.c_contiguous):
             raise ValueError("score_out must be a contiguous int32 array with one entry per target of the slice")
         # the C side writes every entry of its outputs (locations of empty alignments are -1)
-        out = {"score": score_out if score_out is not None else np.empty(n, dtype=np.int32)}
+        def array(key, length, dtype, zeros=False):
+            old = reuse.get(key) if reuse else None
+            if (isinstance(old, np.ndarray) and old.dtype == dtype and old.shape == (length,) and
+                    old.flags.c_contiguous and old.flags.writeable):
+                if zeros:
+                    old[:] = 0
+                return old
+            return np.zeros(length, dtype=dtype) if zeros else np.empty(length, dtype=dtype)
+
+        out = {"score": score_out if score_out is not None else array("score", n, np.int32)}
         et = eq = s_t = s_q = aoff = None
         ops_ptr = ctypes.c_void_p()
         if st >= 1:
-            et = np.empty(n, dtype=np.int32)
-            eq = np.empty(n, dtype=np.int32)
+            et = array("end_t", n, np.int32)
+            eq = array("end_q", n, np.int32)
         if st == 2:
-            s_t = np.empty(n, dtype=np.int32)
-            s_q = np.empty(n, dtype=np.int32)
-            aoff = np.zeros(n + 1, dtype=np.int64)
+            s_t = array("start_t", n, np.int32)
+            s_q = array("start_q", n, np.int32)
+            aoff = array("aln_off", n + 1, np.int64, zeros=True)
         rc = lib().miopalSearchFlat(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
                                     self.alphabet_length, st, MODE[algorithm], start, end,
                                     _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),

@@ -68,6 +68,28 @@ def test_reference_vectors_small_search_routing(capi, vec, mode, small_search_ro
     test_reference_vectors(capi, vec, mode)
 
 
+def test_results_written_into_the_arrays_of_an_earlier_search(capi):
+    """`reuse=`: a caller that searches again with the per-target arrays of an earlier result (pyopal_amd/_capi.py)."""
+    rng = np.random.default_rng(61)
+    res, off = _data.random_db(rng, rng.integers(1, 300, size=3000))
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for mode in ("score", "end", "full"):
+            q1, q2 = _data.random_protein(rng, 40), _data.random_protein(rng, 70)
+            first = db.search(q1, B62, 3, 1, mode, "sw")
+            kept = {k: v for k, v in first.items() if isinstance(v, np.ndarray) and k != "aln_flat"}
+            second = db.search(q2, B62, 3, 1, mode, "sw", reuse=first)
+            for k, v in kept.items():
+                assert second[k] is v, k            # the same arrays, written again
+            ref = _oracle.search(q2, res, off, B62, 3, 1, mode, "sw")
+            compare(second, ref, mode, f"reuse {mode}")
+            # arrays of another shape or type are not taken
+            other = db.search(q2, B62, 3, 1, mode, "sw", 0, 100, reuse=second)
+            assert other["score"] is not second["score"] and len(other["score"]) == 100
+    finally:
+        db.close()
+
+
 @pytest.mark.parametrize("qlen", [65, 150, 300, 1000])
 def test_small_searches_of_longer_queries(capi, small_search_routing, qlen):
     """Production routing of small searches (host_search.inc, kSmallSteps): a few targets against a query of
