@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md, HBM3E spec peak
+RESERVED_CUS = 8       # ranks of a multi-GPU run keep these out of the persistent search launch (room for RCCL's kernels)
 
 
 def parse():
@@ -54,8 +55,32 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` typed bare (no WORLD_SIZE in the environment): start the N ranks as a
+    child `torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line
+    and the child's exit code. This parent never touches the GPU - nothing is imported that could
+    initialise HIP before the child starts, and the child is a child process, not an exec."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL between processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for line in child.stdout:          # rank 0's line (and anything else the ranks print), as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -79,9 +104,6 @@ def main():
     torch.cuda.set_device(local_rank)
     collective = world > 1 or args.force_collective
     if collective:
-        # leave the collective's kernels a few CUs beside the persistent search kernel, so that
-        # the gather of one step really runs during the next step's search
-        os.environ.setdefault("MIOPAL_RESERVE_CUS", "8")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0")
@@ -100,6 +122,11 @@ def main():
     residues, offsets = _data.random_db(rng, np.full(N, L))
     t0 = time.time()
     db = _capi.DeviceDatabase(residues, offsets, 24, device=local_rank)
+    if collective:
+        # leave the collective's kernels a few CUs beside the persistent search kernel, so that
+        # the gather of one step really runs during the next step's search (a handle option:
+        # include/miopal.h, miopalDbSetOption)
+        db.set_option("reserve_cus", RESERVED_CUS)
     # two result buffers: the gather of step k runs beside the search of step k + 1
     outs = [torch.zeros(N, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(2)]
     out = outs[0]
@@ -170,6 +197,11 @@ def main():
     cfg5 = None
     if not args.no_cfg5:
         cfg5 = cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream, collective)
+    if collective:
+        # every timed region is over: the group ends here, so that the other ranks are gone (and their
+        # cores free) while rank 0 times the CPU baseline on its own shard
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         cells_per_step = float(Q) * N * L * world
@@ -250,15 +282,15 @@ def main():
             "score_checksum": checksum,
         }
         line["extras"] = {}
-        if not collective and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (N > 1: rank 0's shard against rank 0's scores - the same 1M x 300 workload per GPU)
             line["cpu_baseline"] = cpu_baseline(query, residues, offsets, matrix, Q, N, L, got)
-            line["extras"] = extras(db, query, matrix, Q, N, L)
+            if not collective:
+                line["extras"] = extras(db, query, matrix, Q, N, L)
         if cfg5 is not None:
             line["extras"]["cfg5_strong"] = cfg5
         print(json.dumps(line), flush=True)
     db.close()
-    if collective:
-        dist.destroy_process_group()
 
 
 def device_results(db, query, matrix, out, stream, Q, N, L):
@@ -473,6 +505,8 @@ def cfg5_strong(args, query, matrix, rank, world, local_rank, on_device, stream,
     offsets = np.arange(n + 1, dtype=np.int64) * length
     t0 = time.time()
     db = _capi.DeviceDatabase(residues, offsets, 24, device=local_rank)
+    if collective:
+        db.set_option("reserve_cus", RESERVED_CUS)
     width = max(bounds[r + 1] - bounds[r] for r in range(world))   # equal-size gather slots
     outs = [torch.zeros(width, dtype=torch.int32, device=f"cuda:{local_rank}") for _ in range(2)]
     db.search_device_scores(query, matrix, outs[0].data_ptr(), stream, 3, 1, "sw")

@@ -189,6 +189,36 @@ int miopalSelfTest(int which);
  */
 void miopalTestInjectFault(int kind, int unit, int spinCap);
 
+/*
+ * Tuning switches (diagnostics and A/B levers; pyopal_amd/csrc/tuning.h lists them). Each is MIOPAL_<NAME>
+ * in the environment, which the library reads ONCE, at its first use of any switch; afterwards a switch
+ * only changes through miopalSetTuning. Nothing on the search path calls getenv: the searches run without
+ * the GIL on many threads (src/pyopal/lib.pyx:1364) and getenv racing another thread's putenv is a data
+ * race in the C library. `name` with or without the MIOPAL_ prefix; value NULL = unset. The change is seen
+ * by searches that start after the call. No reference counterpart.
+ */
+int miopalSetTuning(const char* name, const char* value);
+const char* miopalGetTuning(const char* name);   /* NULL: unset or unknown */
+
+/*
+ * Per-handle options: the two product knobs among the switches, as arguments instead of process-wide
+ * environment (value -1 = back to the process default):
+ *   "reserve_cus"   compute units kept out of the persistent search launches, so that the kernels of a
+ *                   collective that gathers the previous search's scores (one process per GPU, RCCL) find
+ *                   room beside the search (bench.py, multi-GPU ranks: 8); default MIOPAL_RESERVE_CUS / none
+ *   "small_search"  1: searches of few targets may take the wavefront-per-pair kernel (shorter start-up),
+ *                   0: they stay on the lane-per-target kernels; default 1 unless MIOPAL_NO_SMALL_SEARCH
+ */
+int miopalDbSetOption(MiopalDb* db, const char* name, int64_t value);
+
+/*
+ * Test hook: `count` > 0 makes miopalDeviceCount() report that many devices, ordinals 0 .. count - 1 mapped
+ * round-robin onto the physical gfx950 devices, so that the multi-device path of a one-process caller
+ * (pyopal_amd.align: a handle, mirror and stream set per ordinal, hipSetDevice per call,
+ * src/pyopal/_align.py:150-170) runs on a box with one GPU. 0 restores the physical devices.
+ */
+int miopalTestSetLogicalDevices(int count);
+
 #ifdef __cplusplus
 }
 #endif

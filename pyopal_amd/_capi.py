@@ -48,8 +48,9 @@ EXPORTS = [
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalLastRouting", "miopalLastFullRouting", "miopalSearchResults", "miopalReleaseCaches",
+    "miopalSetTuning", "miopalGetTuning", "miopalDbSetOption",
     # test hooks
-    "miopalSelfTest", "miopalTestInjectFault",
+    "miopalSelfTest", "miopalTestInjectFault", "miopalTestSetLogicalDevices",
 ]
 
 
@@ -102,6 +103,14 @@ def lib() -> ctypes.CDLL:
         L.miopalSelfTest.argtypes = [c_int]
         L.miopalTestInjectFault.restype = None
         L.miopalTestInjectFault.argtypes = [c_int, c_int, c_int]
+        L.miopalSetTuning.restype = c_int
+        L.miopalSetTuning.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+        L.miopalGetTuning.restype = ctypes.c_char_p
+        L.miopalGetTuning.argtypes = [ctypes.c_char_p]
+        L.miopalDbSetOption.restype = c_int
+        L.miopalDbSetOption.argtypes = [c_vp, ctypes.c_char_p, c_i64]
+        L.miopalTestSetLogicalDevices.restype = c_int
+        L.miopalTestSetLogicalDevices.argtypes = [c_int]
         L.miopalDbDestroy.restype = None
         L.miopalDbDestroy.argtypes = [c_vp]
         for name in ("miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes"):
@@ -155,6 +164,39 @@ def raise_for(rc: int) -> None:
         raise OverflowError("overflow detected while computing alignment scores")
     detail = last_error()
     raise RuntimeError(f"failed to align to Opal database (code={rc})" + (f": {detail}" if detail else ""))
+
+
+def set_tuning(name: str, value: typing.Optional[str]) -> None:
+    """Set (or, with None, unset) a tuning switch of the library for the searches that start from now on
+    (include/miopal.h, miopalSetTuning; pyopal_amd/csrc/tuning.h lists the switches). The environment is
+    only read once, when the library first looks at a switch: later changes go through here."""
+    rc = lib().miopalSetTuning(name.encode(), None if value is None else str(value).encode())
+    raise_for(rc)
+
+
+def get_tuning(name: str) -> typing.Optional[str]:
+    v = lib().miopalGetTuning(name.encode())
+    return None if v is None else v.decode()
+
+
+class tuning:
+    """``with tuning(NO_BIASED="1", PAIR_STRIPS=None): ...`` - switches set (None: unset) for the block and
+    put back afterwards. Process-wide, like the environment they replace: for tests and A/B tools."""
+
+    def __init__(self, **switches):
+        self._want = switches
+        self._saved = {}
+
+    def __enter__(self):
+        for name, value in self._want.items():
+            self._saved[name] = get_tuning(name)
+            set_tuning(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        for name, value in self._saved.items():
+            set_tuning(name, value)
+        return False
 
 
 def _ptr(a: typing.Optional[np.ndarray]):
@@ -245,6 +287,10 @@ class DeviceDatabase:
 
     def device_bytes(self) -> int:
         return int(lib().miopalDbDeviceBytes(self._h))
+
+    def set_option(self, name: str, value: int) -> None:
+        """Per-handle option (include/miopal.h, miopalDbSetOption): "reserve_cus", "small_search"."""
+        raise_for(lib().miopalDbSetOption(self._h, name.encode(), int(value)))
 
     def search(self, query: np.ndarray, matrix: np.ndarray, gap_open: int = 3, gap_extend: int = 1,
                mode: str = "score", algorithm: str = "sw", start: int = 0,

@@ -29,8 +29,45 @@
 
 #include "../../include/miopal.h"
 #include "common.h"
+#include "tuning.h"
 
 using namespace miopal;
+
+// ---------------------------------------------------------------------------
+// tuning switches (tuning.h): the environment is read here, once, and nowhere else
+// ---------------------------------------------------------------------------
+namespace miopal {
+namespace {
+const char* const kTuningNames[] = {
+#define X(name) "MIOPAL_" #name,
+    MIOPAL_TUNING_SWITCHES(X)
+#undef X
+};
+struct Tuning {
+    std::atomic<const char*> value[(int)Tune::kCount];
+    Tuning() { fromEnv(); }
+    // (copies: a later putenv of the process may not pull a string from under a search)
+    void fromEnv() {
+        for (int k = 0; k < (int)Tune::kCount; ++k) {
+            const char* v = getenv(kTuningNames[k]);
+            value[k].store(v ? strdup(v) : nullptr, std::memory_order_release);
+        }
+    }
+    static Tuning& table() {
+        static Tuning t;   // (thread-safe initialisation)
+        return t;
+    }
+    static int find(const char* name) {
+        if (!name) return -1;
+        if (strncmp(name, "MIOPAL_", 7) == 0) name += 7;
+        for (int k = 0; k < (int)Tune::kCount; ++k)
+            if (strcmp(kTuningNames[k] + 7, name) == 0) return k;
+        return -1;
+    }
+};
+}  // namespace
+const char* tuned(Tune key) { return Tuning::table().value[(int)key].load(std::memory_order_acquire); }
+}  // namespace miopal
 
 // ---------------------------------------------------------------------------
 // errors
@@ -41,6 +78,21 @@ thread_local std::string g_lastError;
 thread_local int64_t g_lastRouting[4] = {0, 0, 0, 0};  // miopalLastRouting
 thread_local int g_lastFullRouting = 0;                // miopalLastFullRouting
 thread_local int g_fault[3] = {0, 0, 0};               // miopalTestInjectFault: kind, unit, spin cap
+// miopalTestSetLogicalDevices: > 0 = that many device ordinals, mapped round-robin onto the physical
+// devices (the multi-device code of a one-process caller - a handle, a stream set, a mirror per
+// ordinal, hipSetDevice per call - on a box with one GPU)
+std::atomic<int> g_logicalDevices{0};
+
+int physicalDeviceCount() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int usable = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    return usable;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -92,7 +144,7 @@ struct PhaseTimer {
         clock_gettime(CLOCK_MONOTONIC, &ts);
         return ts.tv_sec + 1e-9 * ts.tv_nsec;
     }
-    PhaseTimer() : on(getenv("MIOPAL_PHASE_TIMING") != nullptr), t0(now()) {}
+    PhaseTimer() : on(tuned(Tune::PHASE_TIMING) != nullptr), t0(now()) {}
     void mark(const char* what) {
         if (!on) return;
         const double t = now();
@@ -139,7 +191,7 @@ struct HostBytes {
     bool reserve(size_t want) {
         if (want <= cap) return true;
         want = std::max(want, cap + cap / 2);
-        static const bool hugePages = !getenv("MIOPAL_NO_HUGEPAGE");
+        const bool hugePages = !tuned(Tune::NO_HUGEPAGE);
         if (!data && want >= (8u << 20) && hugePages) {
             // a large result buffer is written once, front to back: ask for huge pages so that
             // first touch costs tens of faults instead of tens of thousands
@@ -188,14 +240,43 @@ struct HostBytes {
 extern "C" {
 
 int miopalDeviceCount(void) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    int usable = 0;
-    for (int d = 0; d < n; ++d) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
+    const int physical = physicalDeviceCount();
+    const int logical = g_logicalDevices.load(std::memory_order_relaxed);
+    return (logical > 0 && physical > 0) ? logical : physical;
+}
+
+int miopalTestSetLogicalDevices(int count) {
+    if (count < 0 || count > 64) return fail(MIOPAL_ERR_BAD_ARGUMENT, "logical device count %d not in 0..64", count);
+    g_logicalDevices.store(count, std::memory_order_relaxed);
+    return 0;
+}
+
+int miopalSetTuning(const char* name, const char* value) {
+    const int k = Tuning::find(name);
+    if (k < 0) return fail(MIOPAL_ERR_BAD_ARGUMENT, "unknown tuning switch %s", name ? name : "(null)");
+    // (the old string is left alone: a search on another thread may be reading it)
+    Tuning::table().value[k].store(value ? strdup(value) : nullptr, std::memory_order_release);
+    return 0;
+}
+
+const char* miopalGetTuning(const char* name) {
+    const int k = Tuning::find(name);
+    return k < 0 ? nullptr : tuned((Tune)k);
+}
+
+int miopalDbSetOption(MiopalDb* db, const char* name, int64_t value) {
+    if (!db || !name) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null handle / option name");
+    if (strcmp(name, "reserve_cus") == 0) {
+        if (value < -1 || value > 4096) return fail(MIOPAL_ERR_BAD_ARGUMENT, "reserve_cus %lld out of range", (long long)value);
+        db->optReserveCus.store((int)value, std::memory_order_relaxed);
+        return 0;
     }
-    return usable;
+    if (strcmp(name, "small_search") == 0) {
+        if (value < -1 || value > 1) return fail(MIOPAL_ERR_BAD_ARGUMENT, "small_search takes -1 (default), 0 or 1");
+        db->optSmallSearch.store((int)value, std::memory_order_relaxed);
+        return 0;
+    }
+    return fail(MIOPAL_ERR_BAD_ARGUMENT, "unknown handle option %s", name);
 }
 
 const char* miopalLastError(void) { return g_lastError.c_str(); }
@@ -267,16 +348,20 @@ int miopalDbCreateSubset(MiopalDb** out, const MiopalDb* parent, const int64_t* 
     RC_TRY(uploadOnce(db->device, db->d_offsets, offsets.data(), wantOff));
     if (count > 0) {
         // the residues never leave the device: gathered from the parent's resident copy
-        int64_t* d_src = nullptr;
-        HIP_TRY(hipMalloc(&d_src, (size_t)count * sizeof(int64_t)));
-        int rc = uploadOnce(db->device, d_src, srcStart.data(), (size_t)count * sizeof(int64_t));
-        hipError_t e = hipSuccess;
-        if (rc == 0) {
-            e = launchGatherSequences(parent->d_residues, d_src, db->d_offsets, count, db->d_residues, nullptr);
-            if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-        }
-        (void)hipFree(d_src);
-        if (rc) return rc;
+        // (on a stream of its own: the null stream would serialise against every blocking stream of the process)
+        struct Scratch {
+            int64_t* d_src = nullptr;
+            hipStream_t stream = nullptr;
+            ~Scratch() {
+                if (stream) (void)hipStreamDestroy(stream);
+                if (d_src) (void)hipFree(d_src);
+            }
+        } scratch;
+        HIP_TRY(hipMalloc(&scratch.d_src, (size_t)count * sizeof(int64_t)));
+        HIP_TRY(createUploadStream(&scratch.stream));
+        RC_TRY(uploadOnce(db->device, scratch.d_src, srcStart.data(), (size_t)count * sizeof(int64_t)));
+        hipError_t e = launchGatherSequences(parent->d_residues, scratch.d_src, db->d_offsets, count, db->d_residues, scratch.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(scratch.stream);
         if (e != hipSuccess) return fail(MIOPAL_ERR_HIP, "gathering the subset failed: %s", hipGetErrorString(e));
     }
     db->offsets = std::move(offsets);
@@ -538,8 +623,8 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
     return guarded([&]() -> int {
     if (dbLength <= 0) return 0;
     int device = 0;
-    if (const char* env = getenv("MIOPAL_DEVICE")) device = atoi(env);
-    const bool verbose = getenv("MIOPAL_VERBOSE") != nullptr;
+    if (const char* env = tuned(Tune::DEVICE)) device = atoi(env);
+    const bool verbose = tuned(Tune::VERBOSE) != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     if (!db || !dbSeqLengths) return fail(MIOPAL_ERR_BAD_ARGUMENT, "bad arguments to opalSearchDatabase");
     if (alphabetLength <= 0 || alphabetLength > kMaxAlphabet)
@@ -597,7 +682,7 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
     const auto t2 = std::chrono::steady_clock::now();
     if (rc == 0) {
         int64_t keepMb = 4096;
-        if (const char* env = getenv("MIOPAL_SPARE_HANDLE_MB")) keepMb = atoll(env);
+        if (const char* env = tuned(Tune::SPARE_HANDLE_MB)) keepMb = atoll(env);
         if (handleDeviceBytes(h.get()) <= (keepMb << 20)) {
             SpareHandles& sp = spareHandles();
             std::lock_guard<std::mutex> g(sp.m);

@@ -26,6 +26,7 @@
 //
 // Model and tie-breaks: oracle/opal_oracle.c (rules 5-7).
 #include "common.h"
+#include "tuning.h"
 
 namespace miopal {
 
@@ -783,10 +784,10 @@ hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream) {
         if (mode != kPerPairTrace && a.jobCounter != nullptr && a.queryLength <= kLanes && a.computeUnits > 0) {
             // persistent wavefronts, three per SIMD (163 VGPRs; the HW / OV regions' row select takes 190: two)
             int perCu = mode == kAllCells ? 3 : 2;
-            if (const char* e = getenv("MIOPAL_SCAN_BLOCKS_PER_CU")) perCu = std::max(1, atoi(e));   // (experiments)
+            if (const char* e = tuned(Tune::SCAN_BLOCKS_PER_CU)) perCu = std::max(1, atoi(e));   // (experiments)
             PerPairArgs b = a;
             b.refillLanes = kRefillLanes;
-            if (const char* e = getenv("MIOPAL_SCAN_REFILL_LANES")) b.refillLanes = std::min(64, std::max(1, atoi(e)));
+            if (const char* e = tuned(Tune::SCAN_REFILL_LANES)) b.refillLanes = std::min(64, std::max(1, atoi(e)));
             const int blocks = (int)std::min<int64_t>(((int64_t)a.nJobs + kBlock - 1) / kBlock, (int64_t)a.computeUnits * perCu);
             if (mode == kAllCells) hipLaunchKernelGGL(perpair_scan_refill_kernel<kAllCells>, dim3(blocks), block, lds, stream, b);
             else if (mode == kLastRow) hipLaunchKernelGGL(perpair_scan_refill_kernel<kLastRow>, dim3(blocks), block, lds, stream, b);

@@ -147,6 +147,74 @@ def test_align_arrays_extension_matches_align(mode):
         aligner.align_arrays(seqs[5], db, mode="nope")
 
 
+def _oracle_for(seqs, picks, query, aligner, mode, algo):
+    """The CPU checker's answer for the targets `picks` of `seqs` (test infrastructure: oracle/)."""
+    enc = [_oracle.encode(seqs[k]) for k in picks]
+    res, off = _oracle.flatten(enc)
+    m = np.array(aligner.scoring_matrix.int_array(), dtype=np.int32)
+    return _oracle.search(_oracle.encode(query), res, off, m, aligner.gap_open, aligner.gap_extend, mode, algo)
+
+
+def _assert_arrays_equal_oracle(got, ref, mode, label):
+    np.testing.assert_array_equal(got.score, ref["score"], err_msg=f"{label} score")
+    if mode != "score":
+        np.testing.assert_array_equal(got.query_end, ref["end_q"], err_msg=f"{label} end_q")
+        np.testing.assert_array_equal(got.target_end, ref["end_t"], err_msg=f"{label} end_t")
+    if mode == "full":
+        np.testing.assert_array_equal(got.query_start, ref["start_q"], err_msg=f"{label} start_q")
+        np.testing.assert_array_equal(got.target_start, ref["start_t"], err_msg=f"{label} start_t")
+        assert len(got.operation_offsets) == len(ref["aln"]) + 1
+        for k, ops in enumerate(ref["aln"]):
+            lo, hi = got.operation_offsets[k], got.operation_offsets[k + 1]
+            assert got.operations[lo:hi].tolist() == ops.tolist(), f"{label} operations of target {k}"
+
+
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_align_arrays_and_scores_equal_the_checker(mode):
+    # SURVEY.md section 8f (f3): the bulk results against the CPU checker itself, not only against
+    # Aligner.align - every algorithm, a slice, a query of one strip and one of several
+    rng = np.random.default_rng(78)
+    seqs = ["".join(rng.choice(list(_data.AA20), size=int(n))) for n in rng.integers(1, 160, size=257)]
+    db = pyopal.Database(seqs)
+    aligner = pyopal.Aligner("BLOSUM62", gap_open=3, gap_extend=1)
+    long_query = "".join(rng.choice(list(_data.AA20), size=131))
+    for query in (seqs[5], long_query):
+        for algo in ("nw", "hw", "ov", "sw"):
+            for lo, hi in ((0, 257), (7, 250)):
+                ref = _oracle_for(seqs, range(lo, hi), query, aligner, mode, algo)
+                got = aligner.align_arrays(query, db, mode=mode, algorithm=algo, start=lo, end=hi)
+                _assert_arrays_equal_oracle(got, ref, mode, f"{algo} Q={len(query)} [{lo},{hi})")
+                if mode == "score":
+                    np.testing.assert_array_equal(aligner.scores(query, db, algorithm=algo, start=lo, end=hi), ref["score"])
+
+
+@pytest.mark.parametrize("mode", ["score", "end", "full"])
+def test_subsets_equal_the_checker(mode):
+    # SURVEY.md section 8f (f1): mask / extract / slices (mirrors gathered on the device from the parent's,
+    # miopalDbCreateSubset) and a subset of a subset, against the CPU checker on the same sequences
+    rng = np.random.default_rng(79)
+    seqs = ["".join(rng.choice(list(_data.AA20), size=int(n))) for n in rng.integers(1, 200, size=180)]
+    db = pyopal.Database(seqs)
+    aligner = pyopal.Aligner("BLOSUM62")
+    query = seqs[11]
+    aligner.align(query, db)            # the parent is resident: the subsets below gather from it
+    keep = rng.random(180) < 0.4
+    picks_mask = [k for k in range(180) if keep[k]]
+    picks_extract = [int(k) for k in rng.permutation(180)[:50]] + [3, 3]      # any order, repeats
+    subsets = {"mask": (db.mask(keep.tolist()), picks_mask), "extract": (db.extract(picks_extract), picks_extract),
+               "slice": (db[20:150:3], list(range(20, 150, 3)))}
+    inner = subsets["extract"][0].extract([1, 0, 17])
+    subsets["extract of extract"] = (inner, [picks_extract[1], picks_extract[0], picks_extract[17]])
+    for name, (sub, picks) in subsets.items():
+        assert len(sub) == len(picks), name
+        for algo in ("nw", "hw", "ov", "sw"):
+            ref = _oracle_for(seqs, picks, query, aligner, mode, algo)
+            got = aligner.align_arrays(query, sub, mode=mode, algorithm=algo)
+            _assert_arrays_equal_oracle(got, ref, mode, f"{name} {algo}")
+            objs = aligner.align(query, sub, mode=mode, algorithm=algo)
+            assert [r.score for r in objs] == ref["score"].tolist(), f"{name} {algo} objects"
+
+
 def test_subsets_gather_their_mirror_from_the_parent_on_the_device(monkeypatch):
     # Database.mask / Database.extract / slices (src/pyopal/lib.pyx:694-778 share the parent's buffers):
     # while the parent is resident and unchanged, the subset's mirror is gathered from the parent's on
@@ -195,10 +263,22 @@ def test_align_over_several_real_devices_equals_one_device():
     # device, chunks cut at the shard boundaries, absolute target indices, database order with
     # ordered=True, full alignments - against the answer of device 0 alone. (The per-device launch
     # attributes of the pair-table kernels - 150 KB of dynamic LDS, hipFuncSetAttribute per device - are
-    # exercised by the 53-residue query.) Skipped on a box with one GPU.
+    # exercised by the 53-residue query.) On a box with one GPU: logical devices.
     from pyopal_amd import _capi
-    if _capi.lib().miopalDeviceCount() < 2:
-        pytest.skip("one GPU visible")
+    logical = _capi.lib().miopalDeviceCount() < 2
+    if logical:
+        # one GPU: three device ordinals on it (include/miopal.h, miopalTestSetLogicalDevices) - a handle, a
+        # mirror keyed by (device, shard), a stream set and hipSetDevice per call for each, as with real devices
+        _capi.raise_for(_capi.lib().miopalTestSetLogicalDevices(3))
+    try:
+        _several_devices_equal_one(_capi)
+    finally:
+        if logical:
+            _capi.lib().miopalTestSetLogicalDevices(0)
+
+
+def _several_devices_equal_one(_capi):
+    assert _capi.lib().miopalDeviceCount() >= 2
     rng = np.random.default_rng(12)
     lengths = np.concatenate([rng.integers(200, 600, size=3000), rng.integers(20, 120, size=9000)])   # skewed
     seqs = ["".join(_data.AA20[i] for i in rng.integers(0, 20, size=int(n))) for n in lengths]

@@ -73,6 +73,65 @@ def test_bench_forced_collective_on_one_gpu():
     assert line["extras"]["cfg5_strong"]["gcups"] > 0
 
 
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    # `python bench.py --gpus 2` typed bare, as the driver types it: the parent spawns torch.distributed.run
+    # itself (before anything touches the GPU) and relays rank 0's line. Rehearsal switches for a box with one
+    # GPU: both ranks on cuda:0, gather through gloo. The line is complete at N > 1: roofline, cpu_baseline,
+    # the self-checking cfg5 leg.
+    env = dict(os.environ, MIOPAL_BENCH_SHARE_DEVICE="1", MIOPAL_BENCH_BACKEND="gloo")
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--targets", "50000", "--cfg5-targets", "250000", "--cfg5-steps", "2"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"]["kernel_ms"] > 0 and line["roofline"]["bound"] == "hbm"
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+    strong = line["extras"]["cfg5_strong"]
+    assert "self_check" in strong and len(strong["targets_per_rank"]) == 2 and sum(strong["targets_per_rank"]) == 250000
+    assert "RCCL gather" in line["config"]["workload"]
+
+
+def test_bench_parent_spawns_before_touching_torch(tmp_path):
+    # CPU tier: with --gpus 2 and no WORLD_SIZE the parent must hand over to torch.distributed.run WITHOUT
+    # importing torch (a process that has initialised the GPU must not start the ranks). A stand-in
+    # interpreter records what it was asked to run; the ranks themselves need GPUs (the GPU tier runs them).
+    probe = tmp_path / "probe.py"
+    probe.write_text(
+        "import sys, json, runpy\n"
+        "import bench\n"
+        "seen = {}\n"
+        "class P:\n"
+        "    def __init__(self, cmd, **kw):\n"
+        "        seen['cmd'] = cmd; seen['torch'] = 'torch' in sys.modules; self.stdout = iter(['{\"ok\": 1}\\n'])\n"
+        "    def wait(self): return 7\n"
+        "import subprocess; subprocess.Popen = P\n"
+        "sys.argv = ['bench.py', '--gpus', '2', '--steps', '3']\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    seen['code'] = e.code\n"
+        "print(json.dumps(seen))\n")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(key, None)
+    out = subprocess.run([sys.executable, str(probe)], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert lines[0] == '{"ok": 1}'                      # the child's line is relayed
+    seen = json.loads(lines[-1])
+    assert seen["code"] == 7 and seen["torch"] is False
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+
+
 def test_bench_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -97,3 +97,38 @@ def test_view_cache_survives_a_throwing_builder(capi):
     # the slice would wait on it forever. Needs no device: the builders are injected (miopalSelfTest).
     assert capi.lib().miopalSelfTest(1) == 0
     assert capi.lib().miopalSelfTest(99) != 0    # unknown test number
+
+
+def test_tuning_switches_are_arguments_not_environment(capi, monkeypatch):
+    """include/miopal.h, miopalSetTuning: the library reads MIOPAL_* from the environment once (tests/conftest.py
+    sets MIOPAL_NO_SMALL_SEARCH before the first use); afterwards the environment is not looked at again - a
+    putenv on another thread cannot race a search - and switches change through the call. Needs no device."""
+    assert capi.get_tuning("MIOPAL_NO_SMALL_SEARCH") == "1"          # from the environment, at first use
+    monkeypatch.setenv("MIOPAL_NO_BIASED", "1")
+    assert capi.get_tuning("NO_BIASED") is None                       # the environment is not read again
+    with capi.tuning(NO_BIASED="1", NO_SMALL_SEARCH=None):
+        assert capi.get_tuning("MIOPAL_NO_BIASED") == "1" and capi.get_tuning("NO_SMALL_SEARCH") is None
+    assert capi.get_tuning("NO_BIASED") is None and capi.get_tuning("NO_SMALL_SEARCH") == "1"
+    assert capi.lib().miopalSetTuning(b"NO_SUCH_SWITCH", b"1") == 101
+    assert "unknown tuning switch" in capi.last_error()
+    assert capi.lib().miopalDbSetOption(None, b"reserve_cus", 8) == 101
+    # every switch of the table is documented by name in tuning.h and none is read with getenv elsewhere
+    src = os.path.join(ROOT, "pyopal_amd", "csrc")
+    calls = []
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".inc", ".h")):
+            text = open(os.path.join(src, name)).read()
+            calls += [(name, m.start()) for m in re.finditer(r"\bgetenv\s*\(", re.sub(r"//.*", "", text))]
+    assert [c[0] for c in calls] == ["host.hip"], calls             # Tuning::fromEnv, and nothing else
+
+
+def test_logical_devices_hook_needs_a_physical_device(capi):
+    import torch
+    lib = capi.lib()
+    assert lib.miopalTestSetLogicalDevices(65) == 101
+    assert lib.miopalTestSetLogicalDevices(3) == 0
+    try:
+        # ordinals only exist on top of a real gfx950: without one the count stays 0
+        assert lib.miopalDeviceCount() == (3 if torch.cuda.is_available() else 0)
+    finally:
+        assert lib.miopalTestSetLogicalDevices(0) == 0

@@ -182,11 +182,11 @@ def test_steps_up_beyond_the_guard_band_take_another_flavour(capi):
         db.close()
 
 
-def test_switch_restores_the_half_float_rung(capi, monkeypatch):
+def test_switch_restores_the_half_float_rung(capi, tuning):
     rng = np.random.default_rng(9)
     query = _data.encode(_data.README_QUERY)
     res, off = _data.random_db(rng, rng.integers(20, 300, size=500))
-    monkeypatch.setenv("MIOPAL_NO_BIASED", "1")
+    tuning.setenv("MIOPAL_NO_BIASED", "1")
     db = capi.DeviceDatabase(res, off, 24)
     try:
         got = db.search(query, B62, 3, 1, "score", "sw")
@@ -269,13 +269,13 @@ def test_global_modes_no_target_leaves_the_lanes_for_its_length(capi, algo):
 
 
 @pytest.mark.parametrize("switch", [None, "MIOPAL_NO_BIASED", "MIOPAL_NO_PAIR_TABLE"])
-def test_scores_beyond_the_half_float_range(capi, monkeypatch, switch):
+def test_scores_beyond_the_half_float_range(capi, tuning, switch):
     # match 1024: a copy of the 64-residue query scores 65536, beyond the largest finite half float
     # (65504), where a half-float lane would turn inf and, next to -inf padding, NaN - which converts to
     # 0 and would slip through the "best >= limit" flag. Every rung must hand such lanes on; the answer
     # comes from the int32 kernel whatever the first rung was.
     if switch:
-        monkeypatch.setenv(switch, "1")
+        tuning.setenv(switch, "1")
     rng = np.random.default_rng(64)
     m = scaled_identity(24, 1024, -1024)
     query = _data.random_protein(rng, 64)
@@ -298,13 +298,13 @@ PAIR_STRIPS = 2 + 4            # pair table, one strip after the other (interseq
 
 
 @pytest.fixture(params=["strips", "general"])
-def multi_strip(request, monkeypatch):
+def multi_strip(request, tuning):
     """Both first rungs of a multi-strip Smith-Waterman score search: the pair-table kernel strip by
     strip (default when the scores fit its guard band) and the general kernel's column-shifted lanes."""
     if request.param == "general":
-        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
+        tuning.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
         return GENERAL_SHIFTED
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")   # (also for searches of few units, where the host prefers the general kernel)
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")   # (also for searches of few units, where the host prefers the general kernel)
     return PAIR_STRIPS
 
 
@@ -409,18 +409,18 @@ def test_shifted_lanes_are_not_used_when_the_columns_eat_the_range(capi, multi_s
     shifted_check(capi, query, res, off, B62, 14, 12, expect=multi_strip, tag="ext 12, long targets")
 
 
-def test_switch_restores_the_half_float_rung_of_the_general_kernel(capi, monkeypatch):
+def test_switch_restores_the_half_float_rung_of_the_general_kernel(capi, tuning):
     rng = np.random.default_rng(35)
     query = _data.random_protein(rng, 150)
     res, off = _data.random_db(rng, rng.integers(20, 300, size=500))
-    monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
-    monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_NO_SW_SHIFT", "1")
+    tuning.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     shifted_check(capi, query, res, off, B62, 3, 1, expect=GENERAL_HALF, tag="switch")
 
 
 # --- the strips kernel's own corners ---
-def test_strips_many_rebases_and_long_ragged_groups(capi, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_many_rebases_and_long_ragged_groups(capi, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     # ext 400: the column shift is rebased every other chunk, in every strip at the same chunks (the rows
     # handed from strip to strip must mean the same on both sides); log-normal lengths: groups of very
     # different lengths in one batch, wavefronts that wait at the unit's barrier
@@ -435,8 +435,8 @@ def test_strips_many_rebases_and_long_ragged_groups(capi, monkeypatch):
     shifted_check(capi, query, res, off, B62, 11, 1, expect=PAIR_STRIPS, tag="ext 1")
 
 
-def test_strips_overflow_crosses_strip_boundaries(capi, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_overflow_crosses_strip_boundaries(capi, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     # match 500 on a 200-residue query: copies of 52 residues and more leave the exact range (25600), the
     # pattern that turns inf / NaN in one strip travels down the boundary rows; every such lane is redone
     rng = np.random.default_rng(62)
@@ -452,8 +452,8 @@ def test_strips_overflow_crosses_strip_boundaries(capi, monkeypatch):
 
 
 @pytest.mark.parametrize("A,qlen", [(4, 130), (12, 333), (32, 64), (32, 100), (32, 50)])
-def test_strips_other_alphabets(capi, A, qlen, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_other_alphabets(capi, A, qlen, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     # the pair table of a 33-symbol alphabet holds 36 rows: 64 rows are two strips of 32, 100 rows three
     # of 34; 50 rows would be two strips of 26, below the kernel's 32, and stay on the general kernel
     rng = np.random.default_rng(A * 1000 + qlen)
@@ -474,8 +474,8 @@ def test_strips_other_alphabets(capi, A, qlen, monkeypatch):
     assert (routed[1] == PAIR_STRIPS) == ((A, qlen) != (32, 50))
 
 
-def test_strips_few_groups_long_query(capi, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_few_groups_long_query(capi, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     # 40 strips over 3 batches: the units of a batch run side by side in different workgroups, each
     # wavefront two chunks behind the one above it
     rng = np.random.default_rng(63)
@@ -538,8 +538,8 @@ def strips_end_check(capi, query, res, off, matrix, go, ge, expect=PAIR_STRIPS, 
 
 
 @pytest.mark.parametrize("qlen", [61, 64, 65, 96, 97, 129, 193, 333, 700])
-def test_strips_end_locations_every_kind_of_strip_count(capi, qlen, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_end_locations_every_kind_of_strip_count(capi, qlen, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     rng = np.random.default_rng(7000 + qlen)
     query = _data.random_protein(rng, qlen)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]
@@ -554,11 +554,11 @@ def test_strips_end_locations_every_kind_of_strip_count(capi, qlen, monkeypatch)
     strips_end_check(capi, query, res, off, B62, 11, 1, modes=("end", "full"), tag=f"Q={qlen}")
 
 
-def test_strips_end_locations_ties_across_strips(capi, monkeypatch):
+def test_strips_end_locations_ties_across_strips(capi, tuning):
     # the query repeats one block in every strip: a target holding the block once has equally good
     # alignments ending in the same column at rows of different strips (the smallest row wins), a target
     # holding it twice has them in different columns too (the smallest column wins)
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     rng = np.random.default_rng(71)
     block = _data.random_protein(rng, 30)
     query = np.concatenate([block, _data.random_protein(rng, 14)] * 4)[:170]
@@ -575,8 +575,8 @@ def test_strips_end_locations_ties_across_strips(capi, monkeypatch):
 
 
 @pytest.mark.parametrize("go,ge", [(3, 1), (11, 1), (1, 1), (2, 5), (5, 0), (14, 12)])
-def test_strips_end_locations_gap_models(capi, go, ge, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+def test_strips_end_locations_gap_models(capi, go, ge, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     rng = np.random.default_rng(go * 100 + ge + 72)
     query = _data.random_protein(rng, 150)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=300)]
@@ -585,10 +585,10 @@ def test_strips_end_locations_gap_models(capi, go, ge, monkeypatch):
     strips_end_check(capi, query, res, off, B62, go, ge, expect=None, tag=f"gap {go}/{ge}")
 
 
-def test_strips_end_locations_range_is_left_and_lanes_are_redone(capi, monkeypatch):
+def test_strips_end_locations_range_is_left_and_lanes_are_redone(capi, tuning):
     # strips of 44 rows: 6 row bits, exact below 384; copies of k query residues score 11 k under this
     # matrix: both sides of the limit, in one strip and across several
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
     rng = np.random.default_rng(73)
     m = scaled_identity(24, 11, -4)
     query = _data.random_protein(rng, 130)
@@ -613,23 +613,17 @@ def test_strips_end_locations_probe_declines_scores_in_the_thousands(capi):
     res, off = _data.random_db(rng, np.full(90_000, 600))
     db = capi.DeviceDatabase(res, off, 24)
     try:
-        os.environ["MIOPAL_NO_TWO_PASS_ENDS"] = "1"
-        try:
+        with capi.tuning(NO_TWO_PASS_ENDS="1"):
             db.search(query, B62, 3, 1, "end", "sw")
             assert (capi.DeviceDatabase.last_routing()[1] & 31) == 1
-        finally:
-            del os.environ["MIOPAL_NO_TWO_PASS_ENDS"]
         for go, ge, want in ((3, 1, PAIR_STRIPS), (11, 1, PAIR_STRIPS)):
             got = db.search(query, B62, go, ge, "end", "sw")
             assert (capi.DeviceDatabase.last_routing()[1] & 31) == want, (go, ge)
             ref = _oracle.search(query, res[:off[100]], off[:101], B62, go, ge, "end", "sw")
             for key in ("score", "end_q", "end_t"):
                 np.testing.assert_array_equal(got[key][:100], ref[key], err_msg=f"{go}/{ge} {key}")
-            os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
-            try:
+            with capi.tuning(NO_PAIR_STRIPS="1"):
                 general = db.search(query, B62, go, ge, "end", "sw")
-            finally:
-                del os.environ["MIOPAL_NO_PAIR_STRIPS"]
             for key in ("score", "end_q", "end_t"):
                 np.testing.assert_array_equal(got[key], general[key], err_msg=f"{go}/{ge} {key}: every target")
     finally:
@@ -637,12 +631,12 @@ def test_strips_end_locations_probe_declines_scores_in_the_thousands(capi):
 
 
 @pytest.mark.parametrize("qlen", [65, 97, 130, 193, 333, 700])
-def test_strips_end_locations_in_two_sweeps(capi, qlen, monkeypatch):
+def test_strips_end_locations_in_two_sweeps(capi, qlen, tuning):
     # the second form of multi-strip end locations (scores beyond the row keys' range): a scores-only sweep,
     # then a sweep that looks for each target's known score - first column, then first row, over all strips;
     # targets without a positive cell, ties across strips and columns, lanes beyond 25600 (redone), `full`
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
-    monkeypatch.setenv("MIOPAL_TWO_PASS_ENDS", "1")
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_TWO_PASS_ENDS", "1")
     rng = np.random.default_rng(9000 + qlen)
     query = _data.random_protein(rng, qlen)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 500, size=300)]

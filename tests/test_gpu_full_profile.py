@@ -31,22 +31,22 @@ def capi():
 
 
 @pytest.fixture()
-def lane_per_pair(monkeypatch):
+def lane_per_pair(tuning):
     # (searches of a few hundred targets take the wavefront-per-pair kernels unless told otherwise)
-    monkeypatch.setenv("MIOPAL_NO_SMALL_SEARCH", "1")
-    monkeypatch.setenv("MIOPAL_NO_HYBRID_TRACE", "1")
-    monkeypatch.setenv("MIOPAL_FORCE_LANE_PER_PAIR", "1")   # (the cost estimates prefer a wavefront per pair on few pairs)
+    tuning.setenv("MIOPAL_NO_SMALL_SEARCH", "1")
+    tuning.setenv("MIOPAL_NO_HYBRID_TRACE", "1")
+    tuning.setenv("MIOPAL_FORCE_LANE_PER_PAIR", "1")   # (the cost estimates prefer a wavefront per pair on few pairs)
 
 
-def both_forms(capi, monkeypatch, q, res, off, matrix, go, ge, algo="sw", expect_profile=True):
+def both_forms(capi, tuning, q, res, off, matrix, go, ge, algo="sw", expect_profile=True):
     db = capi.DeviceDatabase(res, off, 24)
     try:
         new = db.search(q, matrix, go, ge, "full", algo)
         routing = capi.DeviceDatabase.last_full_routing()
-        monkeypatch.setenv("MIOPAL_NO_PERPAIR_PROFILE", "1")
+        tuning.setenv("MIOPAL_NO_PERPAIR_PROFILE", "1")
         old = db.search(q, matrix, go, ge, "full", algo)
         assert capi.DeviceDatabase.last_full_routing() & 10 == 0
-        monkeypatch.delenv("MIOPAL_NO_PERPAIR_PROFILE")
+        tuning.delenv("MIOPAL_NO_PERPAIR_PROFILE")
     finally:
         db.close()
     if expect_profile and off[-1] >= 4:
@@ -60,7 +60,7 @@ def both_forms(capi, monkeypatch, q, res, off, matrix, go, ge, algo="sw", expect
 
 @pytest.mark.parametrize("algo", ["sw", "hw", "ov"])
 @pytest.mark.parametrize("qlen", [1, 8, 33, 53, 64])
-def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen, algo):
+def test_one_strip_scan_without_refill(capi, lane_per_pair, tuning, qlen, algo):
     # the start-cell scan of a one-strip query on the kernel that longer queries use (a wavefront lasts as long as
     # its longest lane), against the persistent one and the checker
     rng = np.random.default_rng(500 + qlen)
@@ -70,7 +70,7 @@ def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen, a
     try:
         refill = db.search(q, B62, 3, 1, "full", algo)
         assert capi.DeviceDatabase.last_full_routing() & 32
-        monkeypatch.setenv("MIOPAL_NO_SCAN_REFILL", "1")
+        tuning.setenv("MIOPAL_NO_SCAN_REFILL", "1")
         plain = db.search(q, B62, 3, 1, "full", algo)
         assert capi.DeviceDatabase.last_full_routing() & 35 == 3
     finally:
@@ -82,32 +82,32 @@ def test_one_strip_scan_without_refill(capi, lane_per_pair, monkeypatch, qlen, a
 
 @pytest.mark.parametrize("qlen", [1, 5, 8, 9, 31, 32, 33, 53, 63, 64, 65, 96, 97, 128, 150, 300])
 @pytest.mark.parametrize("gaps", [(3, 1), (11, 1), (1, 1), (5, 5)])
-def test_against_the_checker(capi, lane_per_pair, monkeypatch, qlen, gaps):
+def test_against_the_checker(capi, lane_per_pair, tuning, qlen, gaps):
     rng = np.random.default_rng(1000 * qlen + gaps[0])
     lengths = rng.integers(1, 400, size=600)
     res, off = _data.random_db(rng, lengths)
     q = _data.random_protein(rng, qlen)
-    new, old = both_forms(capi, monkeypatch, q, res, off, B62, *gaps)
+    new, old = both_forms(capi, tuning, q, res, off, B62, *gaps)
     ref = _oracle.search(q, res, off, B62, gaps[0], gaps[1], "full", "sw")
     compare(new, ref, "full", f"profile form Q={qlen} gaps {gaps}")
     compare(old, ref, "full", f"form before Q={qlen} gaps {gaps}")
 
 
 @pytest.mark.parametrize("algo", ["nw", "hw", "ov"])
-def test_other_modes_take_the_profile_form_too(capi, lane_per_pair, monkeypatch, algo):
+def test_other_modes_take_the_profile_form_too(capi, lane_per_pair, tuning, algo):
     # HW / OV: start cells in the regions "last row" / "last row or column" (the lane's last query row picked out of
     # the 64 registers every column; the whole last column for OV); NW: no scan; the direction pass is shared
     rng = np.random.default_rng(77)
     res, off = _data.random_db(rng, rng.integers(1, 300, size=500))
     for qlen in (1, 20, 63, 64, 65, 130, 200):
         q = _data.random_protein(rng, qlen)
-        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1, algo)
+        new, old = both_forms(capi, tuning, q, res, off, B62, 3, 1, algo)
         ref = _oracle.search(q, res, off, B62, 3, 1, "full", algo)
         compare(new, ref, "full", f"{algo} Q={qlen}")
         compare(old, ref, "full", f"{algo} Q={qlen} (form before)")
 
 
-def test_related_sequences(capi, lane_per_pair, monkeypatch):
+def test_related_sequences(capi, lane_per_pair, tuning):
     # long alignments with ties: mutated copies of the query, cheap and dear gaps, two matrices
     rng = np.random.default_rng(5)
     for qlen in (60, 200):
@@ -131,13 +131,13 @@ def test_related_sequences(capi, lane_per_pair, monkeypatch):
         res = np.concatenate(seqs)
         for matrix in (B62, B50):
             for go, ge in ((3, 1), (11, 1), (2, 2)):
-                new, old = both_forms(capi, monkeypatch, q, res, off, matrix, go, ge)
+                new, old = both_forms(capi, tuning, q, res, off, matrix, go, ge)
                 ref = _oracle.search(q, res, off, matrix, go, ge, "full", "sw")
                 compare(new, ref, "full", f"related Q={qlen} gaps {go}/{ge}")
                 compare(old, ref, "full", f"related Q={qlen} gaps {go}/{ge} (form before)")
 
 
-def test_short_targets_at_both_ends_of_the_database(capi, lane_per_pair, monkeypatch):
+def test_short_targets_at_both_ends_of_the_database(capi, lane_per_pair, tuning):
     # the four-residue loads are clamped into the database: the first targets (reversed prefixes reach below
     # their first residue) and the last ones (forward windows reach beyond the last residue) are the ones
     # where the clamp moves the load
@@ -149,23 +149,23 @@ def test_short_targets_at_both_ends_of_the_database(capi, lane_per_pair, monkeyp
         # (a residue that matches, so that the tiny targets do have alignments)
         res[:first] = q[:first]
         res[off[-2]:] = q[-last:]
-        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1)
+        new, old = both_forms(capi, tuning, q, res, off, B62, 3, 1)
         ref = _oracle.search(q, res, off, B62, 3, 1, "full", "sw")
         compare(new, ref, "full", f"ends {first}/{last}")
         compare(old, ref, "full", f"ends {first}/{last} (form before)")
 
 
-def test_a_database_of_fewer_than_four_residues(capi, lane_per_pair, monkeypatch):
+def test_a_database_of_fewer_than_four_residues(capi, lane_per_pair, tuning):
     q = _data.random_protein(np.random.default_rng(3), 30)
     for lengths in ([1], [2], [1, 2], [3]):
         res = q[:sum(lengths)].copy()
         off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1)
+        new, old = both_forms(capi, tuning, q, res, off, B62, 3, 1)
         ref = _oracle.search(q, res, off, B62, 3, 1, "full", "sw")
         compare(new, ref, "full", f"tiny {lengths}")
 
 
-def test_scores_beyond_the_byte_leave_the_form(capi, lane_per_pair, monkeypatch):
+def test_scores_beyond_the_byte_leave_the_form(capi, lane_per_pair, tuning):
     # score + open does not fit a signed byte: the search takes the kernels of before (same answers)
     rng = np.random.default_rng(21)
     res, off = _data.random_db(rng, rng.integers(1, 200, size=300))
@@ -183,7 +183,7 @@ def test_scores_beyond_the_byte_leave_the_form(capi, lane_per_pair, monkeypatch)
 
 
 @pytest.mark.parametrize("algo", ["hw", "ov"])
-def test_many_pairs_of_the_other_modes(capi, monkeypatch, algo):
+def test_many_pairs_of_the_other_modes(capi, tuning, algo):
     # the regions "last row" / "last row or column" at a size where the host picks one lane per pair by itself:
     # every alignment against the kernels of before, a sample against the checker
     rng = np.random.default_rng(41)
@@ -191,7 +191,7 @@ def test_many_pairs_of_the_other_modes(capi, monkeypatch, algo):
     res, off = _data.random_db(rng, lengths)
     for qlen in (53, 150):
         q = _data.random_protein(rng, qlen)
-        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1, algo)
+        new, old = both_forms(capi, tuning, q, res, off, B62, 3, 1, algo)
         for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
             np.testing.assert_array_equal(new[key], old[key], err_msg=f"{key} {algo} Q={qlen}")
         pick = np.sort(rng.choice(len(lengths), size=200, replace=False))
@@ -203,7 +203,7 @@ def test_many_pairs_of_the_other_modes(capi, monkeypatch, algo):
             assert new["aln"][k].tolist() == ref["aln"][x].tolist(), f"alignment of target {k} {algo} Q={qlen}"
 
 
-def test_many_pairs_in_batches(capi, monkeypatch):
+def test_many_pairs_in_batches(capi, tuning):
     # enough pairs for several direction batches and for the copy of one batch's operations beside the
     # next batch; every alignment against the form before
     rng = np.random.default_rng(31)
@@ -211,7 +211,7 @@ def test_many_pairs_in_batches(capi, monkeypatch):
     res, off = _data.random_db(rng, lengths)
     for qlen in (53, 150):
         q = _data.random_protein(rng, qlen)
-        new, old = both_forms(capi, monkeypatch, q, res, off, B62, 3, 1)   # (asserts the profile form ran)
+        new, old = both_forms(capi, tuning, q, res, off, B62, 3, 1)   # (asserts the profile form ran)
         for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
             np.testing.assert_array_equal(new[key], old[key], err_msg=f"{key} Q={qlen}")
         # a sample against the checker

@@ -187,7 +187,7 @@ def test_cfg5_whole_database_on_one_gpu(capi):
         db.close()
 
 
-def test_long_pairs_beside_the_packed_kernel_repeatedly(capi, monkeypatch):
+def test_long_pairs_beside_the_packed_kernel_repeatedly(capi, tuning):
     # The int32 kernel's (pair, strip) units run on the side stream BESIDE the packed launch, their rows
     # crossing XCDs behind progress counters. A counter once overtook its rows under exactly this load (one
     # wrong score in twenty searches of configs[3] with its tail): every mode, twelve searches each, against
@@ -199,9 +199,9 @@ def test_long_pairs_beside_the_packed_kernel_repeatedly(capi, monkeypatch):
     db = capi.DeviceDatabase(res, off, 24)
     try:
         for algo in ("nw", "hw", "ov", "sw"):
-            monkeypatch.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
+            tuning.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
             want = db.search(q, B62, 3, 1, "score", algo)["score"]
-            monkeypatch.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
+            tuning.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
             for run in range(12):
                 got = db.search(q, B62, 3, 1, "score", algo)["score"]
                 np.testing.assert_array_equal(got, want, err_msg=f"{algo}, search {run}")

@@ -29,9 +29,9 @@ def capi():
 
 
 @pytest.fixture
-def forced(monkeypatch):
+def forced(tuning):
     # (also for searches of few units, where the host prefers the general kernel)
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
 
 
 def check(capi, algo, query, res, off, matrix, go, ge, modes=("score", "end"), expect=GLOBAL_STRIPS, tag="", alphabet=24):
@@ -198,9 +198,9 @@ def test_routing(capi):
         db.close()
 
 
-def test_switch_restores_the_general_kernel(capi, monkeypatch):
-    monkeypatch.setenv("MIOPAL_PAIR_STRIPS", "1")
-    monkeypatch.setenv("MIOPAL_NO_GLOBAL_STRIPS", "1")
+def test_switch_restores_the_general_kernel(capi, tuning):
+    tuning.setenv("MIOPAL_PAIR_STRIPS", "1")
+    tuning.setenv("MIOPAL_NO_GLOBAL_STRIPS", "1")
     rng = np.random.default_rng(76)
     query = _data.random_protein(rng, 150)
     res, off = mixed_targets(rng, query)

@@ -171,10 +171,10 @@ def test_related_sequences_with_ties(capi, algo):
 
 
 @pytest.mark.parametrize("switch", ["MIOPAL_NO_PAIR_TABLE", "MIOPAL_NO_DIAG_SHIFT"])
-def test_alternative_kernel_variants(capi, monkeypatch, switch):
+def test_alternative_kernel_variants(capi, tuning, switch):
     # the variants the default dispatch does not pick on small inputs: v_perm profile
     # fetch for one-strip SW, unshifted signed lanes for NW / HW / OV
-    monkeypatch.setenv(switch, "1")
+    tuning.setenv(switch, "1")
     rng = np.random.default_rng(17)
     res, off = _data.random_db(rng, rng.integers(1, 500, size=700))
     for qlen in (53, 150, 600):
@@ -187,11 +187,11 @@ def test_alternative_kernel_variants(capi, monkeypatch, switch):
 
 @pytest.mark.parametrize("switch", ["MIOPAL_HOST_TRACEBACK", "MIOPAL_NO_PERPAIR", "MIOPAL_NO_SIDE_STREAM",
                                     "MIOPAL_NO_HYBRID_TRACE"])
-def test_alternative_full_mode_paths(capi, monkeypatch, switch):
+def test_alternative_full_mode_paths(capi, tuning, switch):
     # fallbacks of `full`: traceback batches built on the host, wavefront-per-pair kernels for
     # one-strip queries, long targets recomputed after (not beside) the packed kernel
-    monkeypatch.setenv(switch, "1")
-    monkeypatch.setenv("MIOPAL_NO_SEGMENTS", "1")
+    tuning.setenv(switch, "1")
+    tuning.setenv("MIOPAL_NO_SEGMENTS", "1")
     rng = np.random.default_rng(23)
     lengths = rng.integers(1, 400, size=5000)
     lengths[:40] = rng.integers(2000, 9000, size=40)
@@ -252,14 +252,14 @@ def test_sw_int16_saturation(capi):
 
 
 @pytest.mark.parametrize("first_rung", ["shifted", "half"])
-def test_sw_lane_width_ladder(capi, monkeypatch, first_rung):
+def test_sw_lane_width_ladder(capi, tuning, first_rung):
     # half-float lanes are exact below 2048, int16 lanes below 32767, then int32:
     # thousands of close homologues push most targets past the first rung (so the
     # whole view is redone with int16 lanes), a few past the second. The column-shifted first rung
     # (round 2) holds the 480-residue query's hits itself and only hands the 6500-residue ones on.
     if first_rung == "half":
-        monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
-        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
+        tuning.setenv("MIOPAL_NO_SW_SHIFT", "1")
+        tuning.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     rng = np.random.default_rng(14)
     q = _data.random_protein(rng, 6500)
     short = q[:480].copy()
@@ -378,12 +378,12 @@ def test_errors(capi):
 
 
 @pytest.mark.parametrize("qlen", [53, 24, 64])
-def test_long_groups_beside_the_packed_kernel(capi, qlen, monkeypatch):
+def test_long_groups_beside_the_packed_kernel(capi, qlen, tuning):
     """Variable-length database without segmented views: the longest groups of a one-strip
     Smith-Waterman search are computed by the wavefront-per-pair kernel on a side stream, the
     rest by the lane-per-target kernel - both must agree with the checker, for scores, end
     locations and full alignments. (What NW / HW / OV searches of such a database do.)"""
-    monkeypatch.setenv("MIOPAL_NO_SEGMENTS", "1")
+    tuning.setenv("MIOPAL_NO_SEGMENTS", "1")
     rng = np.random.default_rng(100 + qlen)
     lengths = np.clip(rng.lognormal(5.3, 0.5, size=60_000), 10, 1500).astype(np.int64)
     lengths[rng.integers(0, len(lengths), size=700)] = rng.integers(1500, 3500, size=700)   # long groups
@@ -581,13 +581,13 @@ def test_segmented_views_hw(capi, qlen, gaps, matrix):
 
 
 @pytest.mark.parametrize("config", ["", "4,4", "4,2", "4,1", "8,8", "8,4", "3,1", "6,2", "5,1", "16,8"])
-def test_strip_configurations(capi, monkeypatch, config):
+def test_strip_configurations(capi, tuning, config):
     """Queries of more than 64 rows: every split into strips and wavefronts that the dispatch
     may pick (host.hip, cost model; MIOPAL_STRIPS forces one) gives the checker's scores and end
     locations - including requests that would leave the last strip without a query row, which
     must be refused rather than run."""
     if config:
-        monkeypatch.setenv("MIOPAL_STRIPS", config)
+        tuning.setenv("MIOPAL_STRIPS", config)
     rng = np.random.default_rng(171)
     res, off = _data.random_db(rng, rng.integers(1, 500, size=700))
     for qlen in (65, 100, 150, 200, 333):
@@ -598,14 +598,14 @@ def test_strip_configurations(capi, monkeypatch, config):
 
 
 @pytest.mark.parametrize("config", ["4,4", "4,2", "4,1", "8,4", "8,2", "6,2", "5,1", "16,8", "12,4"])
-def test_unit_mode_of_multi_round_score_searches(capi, monkeypatch, config):
+def test_unit_mode_of_multi_round_score_searches(capi, tuning, config):
     """Scores of queries whose strips take several rounds: with MIOPAL_UNITS=1 a workgroup takes
     (group, round) units from a counter instead of owning a group; boundary rows and the partial
     answers of a wavefront travel through HBM between rounds, possibly between workgroups. Every
     algorithm (the all-cells maximum of SW and the last-row / last-column answers of HW / OV are
     carried across rounds), ragged groups, more units than workgroups can be resident."""
-    monkeypatch.setenv("MIOPAL_STRIPS", config)
-    monkeypatch.setenv("MIOPAL_UNITS", "1")
+    tuning.setenv("MIOPAL_STRIPS", config)
+    tuning.setenv("MIOPAL_UNITS", "1")
     rng = np.random.default_rng(173)
     seqs = [_data.random_protein(rng, int(n)) for n in rng.integers(1, 400, size=1500)]
     for qlen in (150, 333, 700):
@@ -618,13 +618,13 @@ def test_unit_mode_of_multi_round_score_searches(capi, monkeypatch, config):
 
 
 @pytest.mark.parametrize("first_rung", ["shifted", "half"])
-def test_segmented_view_with_lanes_leaving_the_half_float_range(capi, monkeypatch, first_rung):
+def test_segmented_view_with_lanes_leaving_the_half_float_range(capi, tuning, first_rung):
     """A window whose lane saturates the half-float rung (scores >= 2048) is flagged like any other
     lane, and its target recomputed whole by the next rungs - over the merged window maxima. The
     column-shifted first rung of round 2 (ArithSwU16) holds these scores itself: nothing is redone."""
     if first_rung == "half":
-        monkeypatch.setenv("MIOPAL_NO_SW_SHIFT", "1")
-        monkeypatch.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
+        tuning.setenv("MIOPAL_NO_SW_SHIFT", "1")
+        tuning.setenv("MIOPAL_NO_PAIR_STRIPS", "1")
     rng = np.random.default_rng(5)
     lengths = np.clip(rng.lognormal(5.3, 0.5, size=20_000), 10, 1500).astype(np.int64)
     lengths[:30] = rng.integers(4000, 7000, size=30)
@@ -685,7 +685,7 @@ def test_outlier_windows_in_the_direction_pass(capi):
 
 
 @pytest.mark.parametrize("qlen", [65, 128, 129, 300])
-def test_long_pairs_one_wavefront_per_strip(capi, qlen, monkeypatch):
+def test_long_pairs_one_wavefront_per_strip(capi, qlen, tuning):
     """The wavefront-per-pair int32 kernel with the strips of a pair side by side (intraseq_strips_kernel):
     targets too long for a lane each (> 8192 residues), all modes, scores and end locations, lengths
     that are no multiple of the 64-column blocks, repeats (ties between strips) - against the checker and
@@ -703,9 +703,9 @@ def test_long_pairs_one_wavefront_per_strip(capi, qlen, monkeypatch):
             compare(gpu, ref, mode, f"strip units {algo}/{mode}/Q={qlen}")
             if algo in ("nw", "ov"):   # (SW and HW searches see long targets through windows on the packed kernel)
                 assert capi.DeviceDatabase.last_routing()[0] >= len(long_ones)   # the long pairs went to the int32 kernel
-            monkeypatch.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
+            tuning.setenv("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
             old, _ = run_both(capi, query, res, off, B62, 11, 1, mode, algo)
-            monkeypatch.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
+            tuning.delenv("MIOPAL_NO_PAIR_STRIP_UNITS")
             compare(old, ref, mode, f"strip after strip {algo}/{mode}/Q={qlen}")
 
 
@@ -726,9 +726,7 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
         pinned = torch.empty(9000, dtype=torch.int32).pin_memory().numpy()
         plain = np.empty(9000, dtype=np.int32)
         for switch in (None, "MIOPAL_NO_HOST_SCATTER", "MIOPAL_NO_DIRECT_SCATTER", "MIOPAL_NO_CALLER_PINNED"):
-            if switch:
-                os.environ[switch] = "1"
-            try:
+            with capi.tuning(**({switch: "1"} if switch else {})):
                 for lo, hi in ((0, 9000), (1, 9000), (4000, 4001), (137, 8999)):
                     got = db.search(query, B62, 3, 1, "score", "sw", lo, hi)["score"]
                     np.testing.assert_array_equal(got, want[lo:hi], err_msg=f"{switch} [{lo},{hi})")
@@ -741,9 +739,6 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
                         db.search(query, B62, 3, 1, "score", "sw", lo, hi, score_out=buf[: hi - lo])
                         np.testing.assert_array_equal(buf[: hi - lo], want[lo:hi], err_msg=f"{switch} [{lo},{hi}) into a buffer")
                         assert (buf[hi - lo:] == -7).all()
-            finally:
-                if switch:
-                    del os.environ[switch]
         # a result array that starts INSIDE a pinned allocation: the kernel must write at that address
         big = torch.empty(3 * 9000, dtype=torch.int32).pin_memory().numpy()
         big[:] = -7
@@ -752,5 +747,38 @@ def test_scores_written_by_the_kernel_into_database_order(capi):
         assert (big[:9000] == -7).all() and (big[18000:] == -7).all()
         with pytest.raises(ValueError):
             db.search(query, B62, 3, 1, "score", "sw", score_out=np.empty(5, dtype=np.int32))
+    finally:
+        db.close()
+
+
+@pytest.mark.parametrize("algo", ["sw", "nw", "hw", "ov"])
+def test_refused_pair_table_launch_with_host_visible_outputs(capi, algo, tuning):
+    # A one-strip search hands the pair-table kernel host-visible result arrays (the library's pinned staging
+    # buffer, or the caller's own pinned array). When the runtime refuses that launch (its 150 KB of dynamic
+    # LDS, say) the score pass starts over on the general kernel, which writes the DEVICE arrays: the result
+    # must come from there, not from the host-visible buffer nothing wrote (round-3 advisor finding).
+    import torch
+    rng = np.random.default_rng(405)
+    query = _oracle.encode(_data.README_QUERY)
+    res, off = _data.random_db(rng, rng.integers(1, 300, size=6000))
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for mode in ("score", "end"):
+            ref = _oracle.search_parallel(query, res, off, B62, 3, 1, mode, algo)
+            plain = db.search(query, B62, 3, 1, mode, algo)
+            compare(plain, ref, mode, f"{algo}/{mode}")
+            routed = capi.DeviceDatabase.last_routing()[1]
+            assert (routed & 15) in (4, 5) and not (routed & 16), routed      # the pair-table kernels ran
+            tuning.setenv("MIOPAL_TEST_REFUSE_PAIR_LAUNCH", "1")
+            for pinned in (False, True):
+                buf = (torch.empty(6000, dtype=torch.int32).pin_memory().numpy() if pinned
+                       else np.empty(6000, dtype=np.int32))
+                buf[:] = -7
+                got = db.search(query, B62, 3, 1, mode, algo, score_out=buf)
+                routed = capi.DeviceDatabase.last_routing()[1]
+                assert (routed & 15) == 1 or (routed & 16), "the general kernel took over"
+                compare(got, ref, mode, f"{algo}/{mode} refused, pinned={pinned}")
+                np.testing.assert_array_equal(buf, ref["score"])
+            tuning.delenv("MIOPAL_TEST_REFUSE_PAIR_LAUNCH")
     finally:
         db.close()

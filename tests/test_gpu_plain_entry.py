@@ -178,7 +178,7 @@ def test_concurrent_callers_each_get_their_own_answer(capi):
         np.testing.assert_array_equal(got[t], want, err_msg=f"thread {t}")
 
 
-def test_cache_controls(capi, monkeypatch):
+def test_cache_controls(capi, tuning):
     import torch
     rng = np.random.default_rng(96)
     q = _oracle.encode(_data.README_QUERY)
@@ -194,6 +194,6 @@ def test_cache_controls(capi, monkeypatch):
     assert free0 - torch.cuda.mem_get_info()[0] <= held + (16 << 20), "a second call re-uses it"
     capi.lib().miopalReleaseCaches()
     assert free0 - torch.cuda.mem_get_info()[0] <= 16 << 20, "miopalReleaseCaches gives the memory back"
-    monkeypatch.setenv("MIOPAL_SPARE_HANDLE_MB", "0")
+    tuning.setenv("MIOPAL_SPARE_HANDLE_MB", "0")
     np.testing.assert_array_equal(plain_search(capi, q, res, off, B62, 24)["score"][:100], ref)
     assert free0 - torch.cuda.mem_get_info()[0] <= 16 << 20, "nothing is kept with MIOPAL_SPARE_HANDLE_MB=0"

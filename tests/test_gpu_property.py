@@ -63,12 +63,8 @@ def test_random_cases_match_the_checker(capi, case):
         # lane-per-target kernels (the tier's default), then the production routing of small
         # searches (wavefront-per-pair kernels)
         runs = [db.search(query, matrix.ravel(), go, ge, mode, algo)]
-        saved = os.environ.pop("MIOPAL_NO_SMALL_SEARCH", None)
-        try:
+        with capi.tuning(NO_SMALL_SEARCH=None):
             runs.append(db.search(query, matrix.ravel(), go, ge, mode, algo))
-        finally:
-            if saved is not None:
-                os.environ["MIOPAL_NO_SMALL_SEARCH"] = saved
     finally:
         db.close()
     for gpu in runs:

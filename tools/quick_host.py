@@ -24,8 +24,9 @@ ref = None
 for label, env in (("direct scatter", {}), ("no host scatter", {"MIOPAL_NO_HOST_SCATTER": "1"}),
                    ("no direct scatter", {"MIOPAL_NO_DIRECT_SCATTER": "1"}), ("direct scatter", {})):
     for k in ("MIOPAL_NO_HOST_SCATTER", "MIOPAL_NO_DIRECT_SCATTER"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+        _capi.set_tuning(k, None)
+    for name, value in env.items():
+        _capi.set_tuning(name, value)
     for _ in range(5):
         db.search_device_scores(q, m, out.data_ptr(), stream, 3, 1, "sw")
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -32,10 +32,10 @@ for dist, n in cases:
     for qlen in (65, 150, 300, 1000):
         q = _data.random_protein(np.random.default_rng(qlen), qlen)
         for algo in ("sw", "nw"):
-            os.environ.pop("MIOPAL_PAIR_STRIPS", None)
+            _capi.set_tuning("MIOPAL_PAIR_STRIPS", None)
             a, ra = best_of(db, q, "score", algo)
-            os.environ["MIOPAL_PAIR_STRIPS"] = "1"
+            _capi.set_tuning("MIOPAL_PAIR_STRIPS", "1")
             b, rb = best_of(db, q, "score", algo)
-            os.environ.pop("MIOPAL_PAIR_STRIPS", None)
+            _capi.set_tuning("MIOPAL_PAIR_STRIPS", None)
             print(f"{dist:16s} N={n:8d} Q={qlen:5d} {algo}: default {a:8.3f} ms (code {ra[1]}, side {ra[0]}) | strips forced {b:8.3f} ms (code {rb[1]}, side {rb[0]}) {'<-- strips better' if b < 0.95 * a else ''}", flush=True)
     db.close()

@@ -19,13 +19,13 @@ for dist, n in (("bimodal", 500_000), ("bimodal", 2_000_000), ("lognormal", 500_
         for algo, mode in (("sw", "score"), ("sw", "end"), ("hw", "score")):
             out = []
             for env in ("MIOPAL_SHORT_STRIDE", None):
-                os.environ.pop("MIOPAL_SHORT_STRIDE", None)
-                if env: os.environ[env] = "1"
+                _capi.set_tuning("MIOPAL_SHORT_STRIDE", None)
+                if env: _capi.set_tuning(env, "1")
                 r = db.search(q, m, 3, 1, mode, algo); ts = []
                 for _ in range(3):
                     t = time.perf_counter(); r = db.search(q, m, 3, 1, mode, algo); ts.append(time.perf_counter() - t)
                 out.append((min(ts) * 1e3, r, _capi.DeviceDatabase.last_routing()))
-            os.environ.pop("MIOPAL_SHORT_STRIDE", None)
+            _capi.set_tuning("MIOPAL_SHORT_STRIDE", None)
             same = all(np.array_equal(out[0][1][k], out[1][1][k]) for k in out[0][1])
             print(f"{dist:10s} N={n:8d} Q={qlen:4d} {algo} {mode:5s}: short stride {out[0][0]:8.3f} ms {out[0][2]} | adaptive {out[1][0]:8.3f} ms {out[1][2]} | equal {same}", flush=True)
             assert same

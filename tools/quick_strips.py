@@ -35,9 +35,9 @@ def timed(q, reps=5):
 
 for Q in QS:
     q = _data.random_protein(rng, Q)
-    os.environ.pop("MIOPAL_NO_PAIR_STRIPS", None)
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIPS", None)
     a, ta, ra, ka = timed(q)
-    os.environ["MIOPAL_NO_PAIR_STRIPS"] = "1"
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIPS", "1")
     b, tb, rb, kb = timed(q)
     same = all(bool(np.array_equal(a[k], b[k])) for k in a)
     cells = float(Q) * float(off[-1])

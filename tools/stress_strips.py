@@ -12,7 +12,7 @@ from pyopal_amd.matrices import ScoringMatrix
 
 m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
 ITER = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-os.environ["MIOPAL_PAIR_STRIPS"] = "1"   # also where the host would prefer the general kernel (few units)
+_capi.set_tuning("MIOPAL_PAIR_STRIPS", "1")   # also where the host would prefer the general kernel (few units)
 rng = np.random.default_rng(17)
 cases = [
     ("100k x 2000, Q=2000", np.full(100_000, 2000), 2000, max(1, ITER // 4), "score"),
@@ -36,10 +36,10 @@ for case in cases:
     res, off = _data.random_db(rng, lengths)
     q = _data.random_protein(rng, Q)
     db = _capi.DeviceDatabase(res, off, 24)
-    os.environ[off_switch] = "1"
+    _capi.set_tuning(off_switch, "1")
     want = db.search(q, m, 3, 1, mode, algo)
     assert (_capi.DeviceDatabase.last_routing()[1] & 15) == 1
-    os.environ.pop(off_switch)
+    _capi.set_tuning(off_switch, None)
     bad = 0
     t0 = time.perf_counter()
     for k in range(iters):
@@ -54,14 +54,14 @@ for case in cases:
 
 # ---- the int32 kernel with a pair's strips side by side (intraseq_strips_kernel): the reference's 35 long
 # targets against a 2000-residue query, every mode, against the strip-after-strip kernel's answer
-os.environ.pop("MIOPAL_PAIR_STRIPS", None)
+_capi.set_tuning("MIOPAL_PAIR_STRIPS", None)
 res, off = _data.random_db(rng, np.arange(1000, 35001, 1000))
 q = _data.random_protein(rng, 2000)
 db = _capi.DeviceDatabase(res, off, 24)
 for algo in ("nw", "hw", "ov", "sw"):
-    os.environ["MIOPAL_NO_PAIR_STRIP_UNITS"] = "1"
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
     want = db.search(q, m, 3, 1, "end", algo)
-    os.environ.pop("MIOPAL_NO_PAIR_STRIP_UNITS")
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIP_UNITS", None)
     bad = 0
     t0 = time.perf_counter()
     for k in range(ITER):
@@ -80,9 +80,9 @@ res, off = _data.random_db(rng, lengths)
 q = _data.random_protein(rng, 2000)
 db = _capi.DeviceDatabase(res, off, 24)
 for algo in ("nw", "hw", "ov", "sw"):
-    os.environ["MIOPAL_NO_PAIR_STRIP_UNITS"] = "1"
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIP_UNITS", "1")
     want = db.search(q, m, 3, 1, "score", algo)["score"]
-    os.environ.pop("MIOPAL_NO_PAIR_STRIP_UNITS")
+    _capi.set_tuning("MIOPAL_NO_PAIR_STRIP_UNITS", None)
     bad = 0
     for k in range(ITER):
         got = db.search(q, m, 3, 1, "score", algo)["score"]
