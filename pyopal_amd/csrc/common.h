@@ -165,7 +165,7 @@ struct PerPairArgs {
                               // intraseq_kernel (null: none)
     // > 0: perpair_profile_kernel (every region of the scan but kLastCell, and kPerPairTrace): bytes per residue row of its
     // query profile in LDS (perPairProfileBytes); every job walks the query the same way (`reversed`), and
-    // the directions leave as bit planes: [job / 64][strip][j][rows 0-31 | 32-63][plane][job % 64] dwords
+    // the directions leave as bit planes: [job / 64][strip][j / 4][rows 0-31 | 32-63][job % 64][plane][j % 4] dwords
     int profileStride;
     int reversed;
     int64_t residueCount;     // bytes at `residues` (the profile kernel reads them four at a time, clamped; >= 4)
@@ -310,6 +310,8 @@ hipError_t launchFillInt32(int32_t* out, int n, int32_t value, hipStream_t strea
 // subset of a resident database: dst[dstOff[k] ...] = src[srcStart[k] ...] for every sequence k (dstOff has n + 1 entries)
 // device -> pinned host copy by a small kernel of our own (see pack.hip)
 hipError_t launchCopyOut(const void* src, void* dst, int64_t bytes, hipStream_t stream);
+// units of 64 one-byte operations of `src` -> 16 bytes each of `dst`, two bits per operation (both 16-byte aligned)
+hipError_t launchCopyOutPacked(const void* src, void* dst, int64_t firstUnit, int64_t lastUnit, hipStream_t stream);
 hipError_t launchGatherSequences(const uint8_t* src, const int64_t* srcStart, const int64_t* dstOff, int64_t n,
                                  uint8_t* dst, hipStream_t stream);
 // takeMax: several view positions (segments) may belong to one target; `out` starts at 0

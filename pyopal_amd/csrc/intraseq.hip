@@ -485,8 +485,9 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
     const uint8_t* dirs = head ? a.headDirs + (int64_t)idx * a.headDirStride
                         : laneMajor ? a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + (idx & 63)
                                     : a.dirs + job.dirOff;
-    const bool planes = laneMajor && a.dirPlanes;
-    const uint32_t* planeBase = reinterpret_cast<const uint32_t*>(a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride) + (idx & 63);
+    // (perpair_profile_kernel's bit planes are walked by walk_planes_kernel below; this kernel then only takes the
+    // wavefronts at the head of a hybrid batch, whose directions have intraseq_kernel's layout)
+    if (laneMajor && a.dirPlanes) return;
     const uint8_t* q = a.query + job.qOff;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
     const int slot = a.slotByOut ? job.out : idx;
@@ -517,19 +518,7 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
         }
         const int l = i & 63;
         uint8_t d;
-        if (planes) {
-            // perpair_profile_kernel: bit planes of 32 rows, [strip][column][half][plane][lane] dwords. Most steps
-            // of a path are diagonal: the "from the diagonal" plane first, the "from E" plane only off it; inside a
-            // gap the "opened" plane of that gap
-            const uint32_t* at = planeBase + (((int64_t)(i >> 6) * a.dirStripColumns + j) * 2 + (l >> 5)) * 4 * kLanes;
-            const int bit = 31 - (l & 31);
-            if (state == 0) {
-                d = 0;
-                if (((at[0] >> bit) & 1u) == 0) d = (uint8_t)(((at[kLanes] >> bit) & 1u) ? 1u : 2u);
-            } else {
-                d = (uint8_t)(((at[(state + 1) * kLanes] >> bit) & 1u) ? 12u : 0u);
-            }
-        } else {
+        {
             // perpair_kernel's layout holds two rows per byte ([strip][column][row pair][lane])
             d = laneMajor
                 ? (uint8_t)((dirs[(((int64_t)(i >> 6) * a.dirStripColumns + j) * (kLanes / 2) + (l >> 1)) * kLanes] >> ((l & 1) * 4)) & 0xf)
@@ -566,6 +555,117 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
         for (int x = 0; x < fill; ++x) ops[pos + x] = (uint8_t)(acc >> (8 * x));
     }
     a.opsLen[slot] = len;
+}
+
+// The same walk over perpair_profile_kernel's bit planes (round 4). The planes come in 64-byte lines: the four
+// flags (came from the diagonal / from E / E was opened / F was opened) of FOUR columns x 32 rows of one pair -
+// [pair / 64][strip][column / 4][rows 0-31 | 32-63][pair % 64][plane][column % 4] dwords. A lane's path needs the
+// lines one after the other, each after a round trip to HBM; what round 3 did - a load per step, a different line
+// every step, one dword used of each - cost a memory latency per operation and moved 50 x the bytes the walk
+// needs (profiles/r03_pmc_cfg3full_walk.json). Here the wavefront alternates between two phases: every lane
+// that is not finished fetches the line its path is on (and the eight target residues around it) into LDS - ONE
+// round trip for the whole wavefront - then all lanes step through what they hold, a few cycles a step, until
+// none can go on. A lane that leaves its line early waits for the others; the wavefront pays a latency per line of
+// its longest path, not per step of it.
+__global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
+    __shared__ uint8_t qlds[kWalkQueryLds];
+    __shared__ uint32_t lineLds[16 * 64];   // [plane * 4 + column % 4][lane]: no two lanes share a bank
+    __shared__ uint32_t resLds[2 * 64];     // target residues of the line's four columns (and the bytes before them)
+    for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];   // (launchWalk: the query fits)
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x * 64 + lane;
+    // hybrid direction pass: the wavefronts at the head of the sorted list were done by intraseq_kernel (walk_kernel)
+    if (a.headWaves != nullptr && (int)blockIdx.x < *a.headWaves) return;
+    const bool live = idx < a.nJobs;
+    PairJob job{};
+    if (live) job = a.jobs[idx];
+    const int n = job.qLen, m = job.tLen;
+    const uint32_t* planeBase = reinterpret_cast<const uint32_t*>(a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride) + lane * 16;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
+    const int slot = a.slotByOut ? job.out : idx;
+    uint8_t* ops = a.ops + (int64_t)slot * a.opsSlot;     // (launchWalk: fixed slots, whole dwords)
+    int64_t pos = a.opsSlot;
+    uint32_t acc = 0;
+    int i = n - 1, j = m - 1, state = 0, len = 0;
+    bool probe = false;       // state 0, off the diagonal: is it E?
+    int64_t have = -1;        // the line in LDS (tile index), -1: none
+    auto emit = [&](uint32_t op) {
+        ++len;
+        --pos;
+        acc = (acc << 8) | op;  // the newest operation has the lowest address
+        if ((pos & 3) == 0) *reinterpret_cast<uint32_t*>(ops + pos) = acc;
+    };
+    const int64_t stripTiles = (a.dirStripColumns >> 2) * 2;   // tiles (column block, half) per strip
+    for (;;) {
+        // ---- step while any lane holds what its next step reads
+        for (;;) {
+            const bool walking = live && (i >= 0 || j >= 0);
+            const bool border = walking && (i < 0 || j < 0);
+            const int64_t tile = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
+            const bool can = border || (walking && tile == have);
+            if (__builtin_amdgcn_ballot_w64(can) == 0) break;
+            if (can && i < 0) {          // the rest of the target against nothing
+                emit(2);
+                --j;
+            } else if (can && j < 0) {
+                emit(1);
+                --i;
+            } else if (can) {
+                const int plane = state == 0 ? (probe ? 1 : 0) : state + 1;
+                const uint32_t bit = (lineLds[(plane * 4 + (j & 3)) * 64 + lane] >> (31 - (i & 31))) & 1u;
+                if (state == 0) {
+                    if (probe) {
+                        state = bit ? 1 : 2;
+                        probe = false;
+                    } else if (bit) {
+                        // residue of column j: byte (tOff + j) of the database, out of the two dwords held
+                        const int64_t at = job.tOff + j;
+                        const int64_t first = (job.tOff + (j & ~3)) >> 2;        // dword of the block's first column
+                        const uint32_t w = resLds[(int)((at >> 2) - first) * 64 + lane];
+                        const uint32_t tr = (w >> ((at & 3) * 8)) & 0xffu;
+                        emit(qlds[job.qOff + i] == tr ? 0 : 3);
+                        --i;
+                        --j;
+                    } else {
+                        probe = true;
+                    }
+                } else if (state == 1) {
+                    emit(2);
+                    if (bit) state = 0;
+                    --j;
+                } else {
+                    emit(1);
+                    if (bit) state = 0;
+                    --i;
+                }
+            }
+        }
+        // ---- one round trip: every unfinished lane fetches the line of its current cell
+        const bool walking = live && i >= 0 && j >= 0;
+        if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
+        if (walking) {
+            have = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
+            const uint4* src = reinterpret_cast<const uint4*>(planeBase + have * (kLanes * 16));
+            const int64_t first = (job.tOff + (j & ~3)) >> 2;
+            const uint4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
+            const uint32_t r0 = words[first], r1 = words[first + 1];
+            lineLds[0 * 64 + lane] = p0.x; lineLds[1 * 64 + lane] = p0.y; lineLds[2 * 64 + lane] = p0.z; lineLds[3 * 64 + lane] = p0.w;
+            lineLds[4 * 64 + lane] = p1.x; lineLds[5 * 64 + lane] = p1.y; lineLds[6 * 64 + lane] = p1.z; lineLds[7 * 64 + lane] = p1.w;
+            lineLds[8 * 64 + lane] = p2.x; lineLds[9 * 64 + lane] = p2.y; lineLds[10 * 64 + lane] = p2.z; lineLds[11 * 64 + lane] = p2.w;
+            lineLds[12 * 64 + lane] = p3.x; lineLds[13 * 64 + lane] = p3.y; lineLds[14 * 64 + lane] = p3.z; lineLds[15 * 64 + lane] = p3.w;
+            resLds[lane] = r0;
+            resLds[64 + lane] = r1;
+        }
+    }
+    if (live) {
+        if (pos & 3) {
+            // the lowest dword is only partly filled: its top bytes go out one by one
+            const int fill = 4 - (int)(pos & 3);
+            for (int x = 0; x < fill; ++x) ops[pos + x] = (uint8_t)(acc >> (8 * x));
+        }
+        a.opsLen[slot] = len;
+    }
 }
 
 // Jobs of the start-location pass, built where the end locations already are (HBM):
@@ -932,6 +1032,13 @@ hipError_t launchIntraseqStrips(const IntraseqArgs& a, hipStream_t stream) {
 
 hipError_t launchWalk(const WalkArgs& a, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
+    if (a.dirPlanes) {
+        // (what the query-profile form of the direction pass guarantees: host_full.inc)
+        if (a.dirWaveStride <= 0 || (a.dirStripColumns & 3) || a.opsOff || (a.opsSlot & 3) || a.queryLength > kWalkQueryLds)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(walk_planes_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
+        if (!a.headWaves) return hipGetLastError();
+    }
     hipLaunchKernelGGL(walk_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
     return hipGetLastError();
 }

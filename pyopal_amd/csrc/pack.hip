@@ -196,6 +196,29 @@ hipError_t launchCopyOut(const void* src, void* dst, int64_t bytes, hipStream_t 
     return hipGetLastError();
 }
 
+// The alignment operations on their way to the host, two bits each (codes 0 .. 3, include/opal.h): what a
+// device-to-host copy costs the kernels beside it goes with its BYTES (profiles/r03_full_copy_overlap.txt:
+// two thirds of its own duration, whoever issues it and with however few workgroups), so the operations cross
+// PCIe packed - a quarter of the bytes - and the host unpacks them into the caller's buffer where it used to
+// copy them (host_full.inc, unpackOps). Unit k of 64 operations (bytes [64 k, 64 k + 64) of the compacted
+// stream) becomes the 16 bytes [16 k, 16 k + 16) of `dst`, operation p in bits 2 (p % 4) of byte p / 4.
+__global__ __launch_bounds__(256) void copy_out_packed_kernel(const uint4* src, uint4* dst, int64_t firstUnit,
+                                                              int64_t lastUnit) {
+    const int64_t all = (int64_t)gridDim.x * blockDim.x;
+    auto pack4 = [](uint32_t v) -> uint32_t { return ((v & 0x03030303u) * 0x01041040u) >> 24; };
+    auto pack16 = [&](uint4 v) -> uint32_t { return pack4(v.x) | (pack4(v.y) << 8) | (pack4(v.z) << 16) | (pack4(v.w) << 24); };
+    for (int64_t k = firstUnit + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < lastUnit; k += all)
+        dst[k] = make_uint4(pack16(src[4 * k]), pack16(src[4 * k + 1]), pack16(src[4 * k + 2]), pack16(src[4 * k + 3]));
+}
+
+hipError_t launchCopyOutPacked(const void* src, void* dst, int64_t firstUnit, int64_t lastUnit, hipStream_t stream) {
+    if (lastUnit <= firstUnit) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_out_packed_kernel, dim3(64), dim3(256), 0, stream, (const uint4*)src, (uint4*)dst, firstUnit,
+                       lastUnit);
+    return hipGetLastError();
+}
+
 __global__ void fill_int32_kernel(int32_t* out, int n, int32_t value) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) out[k] = value;

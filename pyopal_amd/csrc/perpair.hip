@@ -242,8 +242,8 @@ __global__ __launch_bounds__(kBlock) void perpair_kernel(PerPairArgs a) {
 //     optimum (once per lane), or - without one - when a column beats the running maximum;
 //   * the direction pass leaves four BIT PLANES per cell (came from the diagonal / from E / E was
 //     opened / F was opened), each shifted in with a subtraction + v_alignbit, stored as dwords of 32
-//     rows, lanes side by side: [pair / 64][strip][column][rows 0-31 | 32-63][plane][pair % 64]. The
-//     walk reads the "diagonal" plane and, off the diagonal, one more.
+//     rows: [pair / 64][strip][column / 4][rows 0-31 | 32-63][pair % 64][plane][column % 4] - the flags of
+//     four columns of a lane's half strip are one 64-byte line (round 4; walk_planes_kernel).
 // Same model and tie-breaks as perpair_kernel (the flags are the same comparisons).
 constexpr int kProfilePad = -128;
 
@@ -303,7 +303,9 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
     uint8_t* dirs = nullptr;
     // (lanes side by side, one dword each: the walk reads one or two planes per step, and the pairs of a
     // wavefront - sorted by length, walking back from similar cells - share its cache lines)
-    if (MODE == kPerPairTrace) dirs = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane * 4;
+    // (round 4: per block of FOUR columns and half strip, one 64-byte line per lane: [plane][column] dwords - every
+    // flag of the cells a path crosses in those columns comes with one line, which the walk fetches once)
+    if (MODE == kPerPairTrace) dirs = a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride + lane * 64;
     // the lane's first row along the profile
     const int yBase = a.reversed ? Qtot - 1 - job.qOff : job.qOff;
 
@@ -371,8 +373,17 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
         } else {
             maxNeed = maxL;
         }
+        // Direction pass: the planes of four columns leave together, 16 bytes per lane and plane (the three
+        // columns before the current one wait in registers; the sweep runs to a multiple of four columns -
+        // pad columns beyond every target, whose bits nobody reads).
+        const int sweep = MODE == kPerPairTrace ? (maxNeed + 3) & ~3 : maxNeed;
+        uint32_t held[3][8];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 8; ++y) held[x][y] = 0;
         int scale = 0;   // j * ext
-        for (int j = 0; j < maxNeed; ++j, scale += ext) {
+        for (int j = 0; j < sweep; ++j, scale += ext) {
             if ((j & 3) == 0) {
                 wcur = inPlace(rawNext, j);
                 rawNext = fetchRaw(j + 4);
@@ -431,19 +442,27 @@ __global__ __launch_bounds__(kBlock) void perpair_profile_kernel(PerPairArgs a) 
                 hmUp = hm;
                 fUp = f;
             }
-            if (toNext) bnd[(int64_t)j * kLanes] = make_int2(hmUp, fUp);
+            if (toNext && j < maxNeed) bnd[(int64_t)j * kLanes] = make_int2(hmUp, fUp);
             if (MODE == kPerPairTrace) {
-                uint32_t* at = (uint32_t*)(dcol + (int64_t)j * (kLanes / 2 * kLanes));
                 // (the bits of the rows a half strip really holds sit at the top of its planes)
-                at[0 * kLanes] = ~pD[0] << pad0;
-                at[1 * kLanes] = ~pE[0] << pad0;
-                at[2 * kLanes] = ~pO[0] << pad0;
-                at[3 * kLanes] = ~pF[0] << pad0;
-                if (rows8 > 32) {
-                    at[4 * kLanes] = ~pD[1] << pad1;
-                    at[5 * kLanes] = ~pE[1] << pad1;
-                    at[6 * kLanes] = ~pO[1] << pad1;
-                    at[7 * kLanes] = ~pF[1] << pad1;
+                uint32_t now[8] = {~pD[0] << pad0, ~pE[0] << pad0, ~pO[0] << pad0, ~pF[0] << pad0,
+                                   ~pD[1] << pad1, ~pE[1] << pad1, ~pO[1] << pad1, ~pF[1] << pad1};
+                if ((j & 3) == 3) {   // wave-uniform
+                    // block of four columns: two tiles (rows 0-31 | 32-63) of 64 lanes x 64 bytes; the four stores of
+                    // a lane fill its line - whole lines leave for HBM
+                    uint8_t* at = dcol + (int64_t)(j >> 2) * (2 * kLanes * 64);
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        if (y >= 4 && rows8 <= 32) break;   // wave-uniform
+                        *(uint4*)(at + (y >> 2) * (kLanes * 64) + (y & 3) * 16) = make_uint4(held[0][y], held[1][y], held[2][y], now[y]);
+                    }
+                } else {
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) {
+                        held[0][y] = held[1][y];
+                        held[1][y] = held[2][y];
+                        held[2][y] = now[y];
+                    }
                 }
                 const bool mine = j == L - 1 && Q > row0 && Q <= row0 + kLanes;  // the lane's last strip
                 if (__builtin_amdgcn_ballot_w64(mine) != 0) {
