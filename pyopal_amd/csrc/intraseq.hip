@@ -570,7 +570,7 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
 __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     __shared__ uint8_t qlds[kWalkQueryLds];
     __shared__ uint32_t lineLds[16 * 64];   // [plane * 4 + column % 4][lane]: no two lanes share a bank
-    __shared__ uint32_t resLds[2 * 64];     // target residues of the line's four columns (and the bytes before them)
+    __shared__ uint32_t resLds[5 * 64];     // the target residues of sixteen columns (five dwords: any alignment)
     for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];   // (launchWalk: the query fits)
     __syncthreads();
     const int lane = threadIdx.x;
@@ -584,17 +584,23 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     const uint32_t* planeBase = reinterpret_cast<const uint32_t*>(a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride) + lane * 16;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
     const int slot = a.slotByOut ? job.out : idx;
-    uint8_t* ops = a.ops + (int64_t)slot * a.opsSlot;     // (launchWalk: fixed slots, whole dwords)
+    uint8_t* ops = a.ops + (int64_t)slot * a.opsSlot;     // (launchWalk: fixed slots of whole 16-byte pieces)
     int64_t pos = a.opsSlot;
-    uint32_t acc = 0;
+    // operations leave 16 bytes at a time (a dword per store left every line of the slot written four times over:
+    // 149 MB of HBM writes for 17 MB of operations, profiles/r04a_pmc_cfg3full_walk_planes_kernel.json)
+    uint32_t acc = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // the dword being filled; whole dwords, w0 the newest
     int i = n - 1, j = m - 1, state = 0, len = 0;
     bool probe = false;       // state 0, off the diagonal: is it E?
     int64_t have = -1;        // the line in LDS (tile index), -1: none
+    int resHave = -1;         // ... and the block of sixteen columns whose residues are
     auto emit = [&](uint32_t op) {
         ++len;
         --pos;
         acc = (acc << 8) | op;  // the newest operation has the lowest address
-        if ((pos & 3) == 0) *reinterpret_cast<uint32_t*>(ops + pos) = acc;
+        if ((pos & 3) == 0) {
+            w3 = w2; w2 = w1; w1 = w0; w0 = acc;
+            if ((pos & 15) == 0) *reinterpret_cast<uint4*>(ops + pos) = make_uint4(w0, w1, w2, w3);
+        }
     };
     const int64_t stripTiles = (a.dirStripColumns >> 2) * 2;   // tiles (column block, half) per strip
     for (;;) {
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
             const bool walking = live && (i >= 0 || j >= 0);
             const bool border = walking && (i < 0 || j < 0);
             const int64_t tile = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
-            const bool can = border || (walking && tile == have);
+            const bool can = border || (walking && tile == have && (j >> 4) == resHave);
             if (__builtin_amdgcn_ballot_w64(can) == 0) break;
             if (can && i < 0) {          // the rest of the target against nothing
                 emit(2);
@@ -619,9 +625,9 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                         state = bit ? 1 : 2;
                         probe = false;
                     } else if (bit) {
-                        // residue of column j: byte (tOff + j) of the database, out of the two dwords held
+                        // residue of column j: byte (tOff + j) of the database, out of the five dwords held
                         const int64_t at = job.tOff + j;
-                        const int64_t first = (job.tOff + (j & ~3)) >> 2;        // dword of the block's first column
+                        const int64_t first = (job.tOff + (j & ~15)) >> 2;       // dword of the block's first column
                         const uint32_t w = resLds[(int)((at >> 2) - first) * 64 + lane];
                         const uint32_t tr = (w >> ((at & 3) * 8)) & 0xffu;
                         emit(qlds[job.qOff + i] == tr ? 0 : 3);
@@ -641,29 +647,50 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                 }
             }
         }
-        // ---- one round trip: every unfinished lane fetches the line of its current cell
+        // ---- one round trip: every unfinished lane fetches the line of its current cell (and, every fourth
+        // time or so, the residues of the next sixteen columns)
         const bool walking = live && i >= 0 && j >= 0;
         if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
         if (walking) {
-            have = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
-            const uint4* src = reinterpret_cast<const uint4*>(planeBase + have * (kLanes * 16));
-            const int64_t first = (job.tOff + (j & ~3)) >> 2;
-            const uint4 p0 = src[0], p1 = src[1], p2 = src[2], p3 = src[3];
-            const uint32_t r0 = words[first], r1 = words[first + 1];
-            lineLds[0 * 64 + lane] = p0.x; lineLds[1 * 64 + lane] = p0.y; lineLds[2 * 64 + lane] = p0.z; lineLds[3 * 64 + lane] = p0.w;
-            lineLds[4 * 64 + lane] = p1.x; lineLds[5 * 64 + lane] = p1.y; lineLds[6 * 64 + lane] = p1.z; lineLds[7 * 64 + lane] = p1.w;
-            lineLds[8 * 64 + lane] = p2.x; lineLds[9 * 64 + lane] = p2.y; lineLds[10 * 64 + lane] = p2.z; lineLds[11 * 64 + lane] = p2.w;
-            lineLds[12 * 64 + lane] = p3.x; lineLds[13 * 64 + lane] = p3.y; lineLds[14 * 64 + lane] = p3.z; lineLds[15 * 64 + lane] = p3.w;
-            resLds[lane] = r0;
-            resLds[64 + lane] = r1;
+            const int64_t tile = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
+            const bool newLine = tile != have, newRes = (j >> 4) != resHave;
+            uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+            if (newLine) {
+                const uint4* src = reinterpret_cast<const uint4*>(planeBase + tile * (kLanes * 16));
+                p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];
+            }
+            if (newRes) {
+                const int64_t first = (job.tOff + (j & ~15)) >> 2;
+                r0 = words[first]; r1 = words[first + 1]; r2 = words[first + 2]; r3 = words[first + 3]; r4 = words[first + 4];
+            }
+            if (newLine) {
+                have = tile;
+                lineLds[0 * 64 + lane] = p0.x; lineLds[1 * 64 + lane] = p0.y; lineLds[2 * 64 + lane] = p0.z; lineLds[3 * 64 + lane] = p0.w;
+                lineLds[4 * 64 + lane] = p1.x; lineLds[5 * 64 + lane] = p1.y; lineLds[6 * 64 + lane] = p1.z; lineLds[7 * 64 + lane] = p1.w;
+                lineLds[8 * 64 + lane] = p2.x; lineLds[9 * 64 + lane] = p2.y; lineLds[10 * 64 + lane] = p2.z; lineLds[11 * 64 + lane] = p2.w;
+                lineLds[12 * 64 + lane] = p3.x; lineLds[13 * 64 + lane] = p3.y; lineLds[14 * 64 + lane] = p3.z; lineLds[15 * 64 + lane] = p3.w;
+            }
+            if (newRes) {
+                resHave = j >> 4;
+                resLds[0 * 64 + lane] = r0; resLds[1 * 64 + lane] = r1; resLds[2 * 64 + lane] = r2;
+                resLds[3 * 64 + lane] = r3; resLds[4 * 64 + lane] = r4;
+            }
         }
     }
     if (live) {
-        if (pos & 3) {
-            // the lowest dword is only partly filled: its top bytes go out one by one
-            const int fill = 4 - (int)(pos & 3);
-            for (int x = 0; x < fill; ++x) ops[pos + x] = (uint8_t)(acc >> (8 * x));
+        // what has not left yet: the partly filled dword's top bytes, then the whole dwords up to the next
+        // 16-byte boundary
+        int64_t at = pos;
+        if (at & 3) {
+            const int fill = 4 - (int)(at & 3);
+            for (int x = 0; x < fill; ++x) ops[at + x] = (uint8_t)(acc >> (8 * x));
+            at += fill;
         }
+        const int whole = (int)(((16 - (at & 15)) & 15) >> 2);
+        if (whole > 0) *reinterpret_cast<uint32_t*>(ops + at) = w0;
+        if (whole > 1) *reinterpret_cast<uint32_t*>(ops + at + 4) = w1;
+        if (whole > 2) *reinterpret_cast<uint32_t*>(ops + at + 8) = w2;
         a.opsLen[slot] = len;
     }
 }
@@ -1034,7 +1061,7 @@ hipError_t launchWalk(const WalkArgs& a, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
     if (a.dirPlanes) {
         // (what the query-profile form of the direction pass guarantees: host_full.inc)
-        if (a.dirWaveStride <= 0 || (a.dirStripColumns & 3) || a.opsOff || (a.opsSlot & 3) || a.queryLength > kWalkQueryLds)
+        if (a.dirWaveStride <= 0 || (a.dirStripColumns & 3) || a.opsOff || (a.opsSlot & 15) || a.queryLength > kWalkQueryLds)
             return hipErrorInvalidValue;
         hipLaunchKernelGGL(walk_planes_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
         if (!a.headWaves) return hipGetLastError();
