@@ -66,6 +66,7 @@ struct InterseqArgs {
     int directN;               // view positions that hold a target
     int stripSpinCap;          // strips kernels: polls (x s_sleep) before a unit gives up on the strip above; 0 = the default
     int faultUnit1;            // strips kernels, test hook: unit (this - 1) behaves as if it had died; 0 = none
+    unsigned long long* stripTiming;   // diagnostic builds (-DMIOPAL_STRIP_TIMING=1, interseq_impl.h): six counters; else null
     uint2* boundary[2];        // ping-pong strip boundaries, same indexing as pack*4
     const int64_t* boundaryOff;
 };
@@ -355,7 +356,9 @@ __host__ __device__ inline int borderGap(int k, int open, int ext) {
 // comparison each in the GPU tier.
 static __device__ __forceinline__ void stripPublish(int* counter, int value, int lane) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifndef MIOPAL_ABL_NO_PUBLISH_WAIT   // (ablation builds only: wrong, timing)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     if (lane == 0) __hip_atomic_store(counter, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // wave-uniform value of the producer's counter; rows may be loaded once it is large enough

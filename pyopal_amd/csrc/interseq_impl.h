@@ -1123,6 +1123,63 @@ static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)v * 0x
 #ifndef MIOPAL_STRIP_PACE
 #define MIOPAL_STRIP_PACE 1
 #endif
+
+// Diagnostic builds of the strips kernels (tools/ab_build.sh; never the product build):
+//   -DMIOPAL_STRIP_TIMING=1   every wavefront adds up s_memtime deltas around its wait sites and leaves them in
+//                             InterseqArgs::stripTiming: [0] taking a unit (counter, the two barriers, the table
+//                             when the strip changes), [1] polling the strip above, [2] the s_waitcnt before
+//                             progress is published, [3] the sweeps (polls and publishes included), [4] the
+//                             wavefront's life, [5] wavefronts (s_memtime comes back through lgkmcnt, so the LDS
+//                             reads in flight are waited for at every mark: the build is slower than the product's)
+//   -DMIOPAL_ABL_NO_POLL / _NO_ROW_LOADS / _NO_ROW_STORES / _NO_PUBLISH_WAIT
+//                             ablations: the same instruction stream without one of the hand-over's parts (wrong
+//                             results, honest timing: what that part costs)
+#ifndef MIOPAL_STRIP_TIMING
+#define MIOPAL_STRIP_TIMING 0
+#endif
+// Boundary rows between strips travel 16 bytes a lane (round 4): {H, F} of TWO neighbouring columns per store /
+// load, [column pair][lane] - the same bytes as before, half the memory instructions. An 8-byte sc1 store is one
+// fabric write per lane at 2.7 x the time per byte of a 16-byte one, an 8-byte sc1 load runs at 0.54-0.70 x the
+// 16-byte rate (MI355X_MICROARCH.md, "stores of each flavour"); the ablation builds below showed each direction of
+// the hand-over costing a cfg4 search 9 % (profiles/r04_strips_ablation.txt). buffer_load / buffer_store
+// dwordx4 with sc1 (the atomics of common.h stop at 8 bytes); the compiler tracks them in vmcnt like any load.
+typedef unsigned int StripU4 __attribute__((ext_vector_type(4)));
+struct StripRows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit StripRows(void* base)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffff0, 0x00020000)) {}
+    __device__ __forceinline__ StripU4 load(int pair, int lane) const {
+#ifdef MIOPAL_ABL_NO_ROW_LOADS
+        return StripU4{0x0a000a00u + (uint32_t)pair, 0x08000800u, 0x0a000a00u, 0x08000800u};
+#else
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, (pair * kLanes + lane) * 16, 0, 16 /* sc1 */);
+#endif
+    }
+    __device__ __forceinline__ void store(int pair, int lane, StripU4 v) const {
+#ifndef MIOPAL_ABL_NO_ROW_STORES
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (pair * kLanes + lane) * 16, 0, 16 /* sc1 */);
+#else
+        asm volatile("" ::"v"(v));
+#endif
+    }
+};
+struct StripTimer {
+#if MIOPAL_STRIP_TIMING
+    unsigned long long t[4] = {0, 0, 0, 0}, mark[4] = {0, 0, 0, 0}, born = __builtin_amdgcn_s_memtime();
+    __device__ __forceinline__ void start(int k) { mark[k] = __builtin_amdgcn_s_memtime(); }
+    __device__ __forceinline__ void stop(int k) { t[k] += __builtin_amdgcn_s_memtime() - mark[k]; }
+    __device__ __forceinline__ void flush(unsigned long long* out, int lane) {
+        if (!out || lane != 0) return;
+        for (int k = 0; k < 4; ++k) atomicAdd(out + k, t[k]);
+        atomicAdd(out + 4, __builtin_amdgcn_s_memtime() - born);
+        atomicAdd(out + 5, 1ull);
+    }
+#else
+    __device__ __forceinline__ void start(int) {}
+    __device__ __forceinline__ void stop(int) {}
+    __device__ __forceinline__ void flush(unsigned long long*, int) {}
+#endif
+};
 constexpr int kPaceInts = 20;   // 4 SIMDs x 4 slots of progress + 4 slot counters
 struct SimdPace {
     int* mine = nullptr;        // this wavefront's progress word
@@ -1505,8 +1562,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
     const int spinCap = a.stripSpinCap > 0 ? a.stripSpinCap : kStripSpinCap;
     SimdPace pace;
     pace.init(ctl + 4, lane);
+    StripTimer timer;
 
     for (;;) {
+        timer.start(0);
         if (threadIdx.x == 0) {
             int next = atomicAdd(a.unitCounter, 1);
             // Too many lanes have left the exact range: the host will redo the whole view on the next
@@ -1520,7 +1579,10 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         }
         __syncthreads();   // (and: every wavefront has left the table of the unit before)
         const int u = __builtin_amdgcn_readfirstlane(ctl[0]);
-        if (u >= nBatches * nStrips) break;
+        if (u >= nBatches * nStrips) {
+            timer.stop(0);
+            break;
+        }
         // strip-major: strip s of every batch before strip s + 1 of any. The wavefront above is then
         // (number of batches) units ahead - usually finished, never just started: with batch-major
         // order every unit began by waiting for the unit taken a moment before it to get two chunks
@@ -1543,6 +1605,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             tableStrip = s;
         }
         __syncthreads();   // table ready; ctl[0] read by everybody
+        timer.stop(0);
         const int gIdx = b * perBatch + wave;
         if (wave >= perBatch || gIdx >= a.nGroups) continue;
         const int g = gIdx + a.groupBase;
@@ -1561,12 +1624,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         // that bypass the local L2), ordered against the progress counter by waiting for the memory
         // operations themselves - release / acquire FENCES at agent scope write back and invalidate
         // the whole L2 each time, 80 us per chunk when every wavefront of the chip does it.
-        unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + a.boundaryOff[g]);
-        unsigned long long* bout = reinterpret_cast<unsigned long long*>(a.boundary[s & 1] + a.boundaryOff[g]);
-        auto loadRow = [&](int col) -> uint2 {
-            const unsigned long long v = __hip_atomic_load(bin + (uint32_t)(col * kLanes + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-        };
+        const StripRows rowsIn(a.boundary[(s + 1) & 1] + a.boundaryOff[g]), rowsOut(a.boundary[s & 1] + a.boundaryOff[g]);
         int* progOut = a.unitFlags + (size_t)gIdx * nStrips + s;
         const int* progIn = progOut - 1;
         const int lastCol = nChunks * 4 - 1;
@@ -1578,6 +1636,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
         const bool injected = u + 1 == a.faultUnit1;
         bool dead = injected;
         auto waitFor = [&](int need) {
+#ifdef MIOPAL_ABL_NO_POLL
+            avail = nChunks;
+#endif
+            if (avail >= need) return;
+            timer.start(1);
             // (wave-uniform: every lane reads the same counter)
             int spins = 0;
             while (avail < need) {
@@ -1589,6 +1652,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 if (a.stripAbort && __hip_atomic_load(a.stripAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= a.stripAbortAt)
                     avail = kStripPoison;
             }
+            timer.stop(1);
             if (avail >= kStripPoison) dead = true;
         };
         if (!dead) waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
@@ -1620,15 +1684,12 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             }
             // row above: column j in hand, the next kRowsAhead columns on their way (the loads go to
             // memory, past the L2: a microsecond or two, a column takes about one)
-            constexpr int kRowsAhead = MIOPAL_STRIP_ROWS_AHEAD;
-            uint2 bq[kRowsAhead + 1];
-#pragma unroll
-            for (int x = 0; x <= kRowsAhead; ++x) bq[x] = make_uint2(fl, zero2);
+            // (two columns per load: the pair in use and the next one on its way - it is asked for at the pair's
+            // first column and first read two columns later)
+            StripU4 pq0 = {fl, zero2, fl, zero2}, pq1 = pq0;
+            uint32_t keepH = 0, keepF = 0;      // the even column's {H, F} waiting for its neighbour's
             uint32_t hbPrev = fl;               // H of the row above at column j - 1 (left border: 0)
-            if constexpr (kFromAbove) {
-#pragma unroll
-                for (int x = 0; x < kRowsAhead; ++x) bq[x] = loadRow(min(x, lastCol));
-            }
+            if constexpr (kFromAbove) pq0 = rowsIn.load(0, lane);
             uint2 cur = pack[lane];
             auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
                 const uint32_t rowIdx = __umul24(tA, (uint32_t)nSym) + tB;
@@ -1637,7 +1698,8 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             };
             // (the second pass of an `end` search has a row scan inside the column loop: it gives the
             // registers of two prefetched blocks of pair-table rows for it)
-            constexpr int kWant = KNOWN ? 1 : R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
+            // (round 4: the boundary rows in 16-byte pairs cost four registers: tall strips give a prefetched block for them)
+            constexpr int kWant = KNOWN ? 1 : R > (LOC ? 38 : 44) ? 2 : MIOPAL_PAIR_AHEAD;
             constexpr int kAhead = NB4 > kWant ? kWant : 1;
             const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
             uint4 vn[kAhead];
@@ -1654,14 +1716,17 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                     if (dead) break;
                 }
                 uint32_t ra = cur.x, rb = cur.y;
-#pragma unroll 1
-                for (int cc = 0; cc < 4; ++cc) {
+                // (the two columns of a pair as two copies of the body: which half of the pair a column reads and
+                // whether it stores are compile-time then - as run-time selects they cost the kernel 24 registers)
+                auto column = [&](auto oddC, int cc) {
+                    constexpr bool odd = decltype(oddC)::value;
                     const int j = c * 4 + cc;
                     const uint4* prow = prowNext;
                     uint4 v[NB4];
 #pragma unroll
                     for (int k = 0; k < kAhead; ++k) v[k] = vn[k];
-                    if constexpr (kFromAbove) bq[kRowsAhead] = loadRow(min(j + kRowsAhead, lastCol));
+                    if constexpr (kFromAbove && !odd) pq1 = rowsIn.load(min(j / 2 + 1, lastCol / 2), lane);
+                    const uint32_t hAbove = odd ? pq0.z : pq0.x, fAbove = odd ? pq0.w : pq0.y;
                     ra = cc < 3 ? ra >> 8 : nxt.x;
                     rb = cc < 3 ? rb >> 8 : nxt.y;
                     prowNext = rowOf(ra & 0xffu, rb & 0xffu);
@@ -1675,7 +1740,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                     fl += ext2;                         // this column's zero
                     uint32_t fl1 = fl + ext2;           // the next column's
                     asm volatile("" : "+v"(fl1));
-                    uint32_t f = kFromAbove ? bq[0].y : fl, cm = fl, held = fl;
+                    uint32_t f = kFromAbove ? fAbove : fl, cm = fl, held = fl;
 #pragma unroll
                     for (int r4 = 0; r4 < NB4; ++r4) {
                         if (r4 + kAhead < NB4) v[r4 + kAhead] = prow[r4 + kAhead];
@@ -1742,12 +1807,21 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                         best = pk_max_u16(best, cm - fl);
                     }
                     // (compiled per kind of strip: a run-time branch here costs 27 registers)
-                    if constexpr (kToBelow)
-                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane), ((unsigned long long)f << 32) | H[R - 1],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hbPrev = bq[0].x;
-#pragma unroll
-                    for (int x = 0; x < kRowsAhead; ++x) bq[x] = bq[x + 1];
+                    if constexpr (kToBelow) {
+                        if constexpr (odd) {
+                            rowsOut.store(j / 2, lane, StripU4{keepH, keepF, H[R - 1], f});
+                        } else {
+                            keepH = H[R - 1];
+                            keepF = f;
+                        }
+                    }
+                    hbPrev = hAbove;
+                    if constexpr (odd) pq0 = pq1;
+                };
+#pragma unroll 1
+                for (int cp = 0; cp < 4; cp += 2) {
+                    column(std::false_type{}, cp);
+                    column(std::true_type{}, cp + 1);
                 }
                 cur = nxt;
                 shift += 4 * ext;
@@ -1767,15 +1841,19 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
                 // (every fourth chunk and the last: the wait below also waits for the loads in flight)
                 if (kToBelow && (((c + 1) & MIOPAL_STRIP_PUBLISH_MASK) == 0 || c + 1 == nChunks)) {
                     // every row store of the chunks has COMPLETED before the counter moves (stripPublish, common.h)
+                    timer.start(2);
                     stripPublish(progOut, c + 1, lane);
+                    timer.stop(2);
                 }
             }
         };
         if (!dead) {
             pace.begin(lane);
+            timer.start(3);
             if (!fromAbove) sweep(std::false_type{}, std::true_type{});
             else if (toBelow) sweep(std::true_type{}, std::true_type{});
             else sweep(std::true_type{}, std::false_type{});
+            timer.stop(3);
             pace.end(lane);
         }
         const size_t base = (size_t)g * kGroupTargets;
@@ -1823,6 +1901,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_strips_kern
             }
         }
     }
+    timer.flush(a.stripTiming, lane);
 }
 
 template <int R, bool LOC, bool KNOWN = false>
@@ -2259,12 +2338,17 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
     const int rl = Q - 1 - (nStrips - 1) * R;   // row of the last query residue inside the last strip
     SimdPace pace;
     pace.init(ctl + 4, lane);
+    StripTimer timer;
 
     for (;;) {
+        timer.start(0);
         if (threadIdx.x == 0) ctl[0] = atomicAdd(a.unitCounter, 1);
         __syncthreads();   // (and: every wavefront has left the table of the unit before)
         const int u = __builtin_amdgcn_readfirstlane(ctl[0]);
-        if (u >= nBatches * nStrips) break;
+        if (u >= nBatches * nStrips) {
+            timer.stop(0);
+            break;
+        }
         const int s = u / nBatches, b = u - s * nBatches;   // strip-major (see interseq_pair_strips_kernel)
         if (s != tableStrip) {
             // s'' = s + 2 ext + c = s + ext + open of both targets as one integer (the diagonal step crosses
@@ -2284,6 +2368,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
             tableStrip = s;
         }
         __syncthreads();   // table ready; ctl[0] read by everybody
+        timer.stop(0);
         const int gIdx = b * perBatch + wave;
         if (wave >= perBatch || gIdx >= a.nGroups) continue;
         const int g = gIdx + a.groupBase;
@@ -2293,12 +2378,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
         if (longGroup) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_setprio(0);
         const bool fromAbove = s > 0, toBelow = s + 1 < nStrips;
-        unsigned long long* bin = reinterpret_cast<unsigned long long*>(a.boundary[(s + 1) & 1] + a.boundaryOff[g]);
-        unsigned long long* bout = reinterpret_cast<unsigned long long*>(a.boundary[s & 1] + a.boundaryOff[g]);
-        auto loadRow = [&](int col) -> uint2 {
-            const unsigned long long v = __hip_atomic_load(bin + (uint32_t)(col * kLanes + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
-        };
+        const StripRows rowsIn(a.boundary[(s + 1) & 1] + a.boundaryOff[g]), rowsOut(a.boundary[s & 1] + a.boundaryOff[g]);
         int* progOut = a.unitFlags + (size_t)gIdx * nStrips + s;
         const int* progIn = progOut - 1;
         const int lastCol = nChunks * 4 - 1;
@@ -2309,6 +2389,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
         const bool injected = u + 1 == a.faultUnit1;
         bool dead = injected;
         auto waitFor = [&](int need) {
+#ifdef MIOPAL_ABL_NO_POLL
+            avail = nChunks;
+#endif
+            if (avail >= need) return;
+            timer.start(1);
             int spins = 0;
             while (avail < need) {
                 avail = stripPoll(progIn);
@@ -2316,6 +2401,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                 __builtin_amdgcn_s_sleep(MIOPAL_STRIP_SLEEP);
                 if (++spins > spinCap) avail = kStripPoison;
             }
+            timer.stop(1);
             if (avail >= kStripPoison) dead = true;
         };
         if (!dead) waitFor(min(kLag + MIOPAL_STRIP_SLACK, nChunks));
@@ -2351,17 +2437,14 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     rowShift += ext;
                 }
             }
-            constexpr int kRowsAhead = MIOPAL_STRIP_ROWS_AHEAD;
-            uint2 bq[kRowsAhead + 1];
-#pragma unroll
-            for (int x = 0; x <= kRowsAhead; ++x) bq[x] = make_uint2(0u, 0u);
+            StripU4 pq0 = {0u, 0u, 0u, 0u}, pq1 = pq0;   // the pair of columns in use, the next one on its way
+            uint32_t keepH = 0, keepF = 0;
             // H of the row above at column j - 1, on that column's scale: the left border of row s R - 1
             uint32_t hbPrev = 0u;
             if constexpr (kFromAbove) {
                 // (stored form on the scale of (-1, -1): one row above the strip's row 0)
                 hbPrev = both(zero - ext + (leftGap ? borderGap(s * R - 1, open, ext) : 0) - ext - (open - ext));
-#pragma unroll
-                for (int x = 0; x < kRowsAhead; ++x) bq[x] = loadRow(min(x, lastCol));
+                pq0 = rowsIn.load(0, lane);
             }
             uint2 cur = pack[lane];
             auto rowOf = [&](uint32_t tA, uint32_t tB) -> const uint4* {
@@ -2369,7 +2452,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                 return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pairs) +
                                                       __umul24(rowIdx, (uint32_t)(SLOTS * 16)));
             };
-            constexpr int kWant = R > 56 ? 2 : MIOPAL_PAIR_AHEAD;
+            constexpr int kWant = R > 50 ? 1 : R > (LOC ? 38 : 44) ? 2 : MIOPAL_PAIR_AHEAD;
             constexpr int kAhead = NB4 > kWant ? kWant : 1;
             const uint4* prowNext = rowOf(cur.x & 0xffu, cur.y & 0xffu);
             uint4 vn[kAhead];
@@ -2388,14 +2471,16 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     if (dead) break;
                 }
                 uint32_t ra = cur.x, rb = cur.y;
-#pragma unroll 1
-                for (int cc = 0; cc < 4; ++cc) {
+                // (the two columns of a pair as two copies of the body: see interseq_pair_strips_kernel)
+                auto column = [&](auto oddC, int cc) {
+                    constexpr bool odd = decltype(oddC)::value;
                     const int j = c * 4 + cc;
                     const uint4* prow = prowNext;
                     uint4 v[NB4];
 #pragma unroll
                     for (int k = 0; k < kAhead; ++k) v[k] = vn[k];
-                    if constexpr (kFromAbove) bq[kRowsAhead] = loadRow(min(j + kRowsAhead, lastCol));
+                    if constexpr (kFromAbove && !odd) pq1 = rowsIn.load(min(j / 2 + 1, lastCol / 2), lane);
+                    const uint32_t hAbove = odd ? pq0.z : pq0.x, fAbove = odd ? pq0.w : pq0.y;
                     ra = cc < 3 ? ra >> 8 : nxt.x;
                     rb = cc < 3 ? rb >> 8 : nxt.y;
                     prowNext = rowOf(ra & 0xffu, rb & 0xffu);
@@ -2408,7 +2493,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     if constexpr (kFromAbove) {
                         dsum = hbPrev + score(0);       // the row above at column j - 1, one column to the right
                         sigma += ext;
-                        f = bq[0].y;                    // F entering the strip's first row, on this column's scale
+                        f = fAbove;                     // F entering the strip's first row, on this column's scale
                     } else {
                         // row above the matrix: H[-1][j-1] in stored form on the scale of (-1, j - 1), the F that
                         // H[-1][j] opens in plain form on the scale of (0, j)
@@ -2452,14 +2537,16 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     if constexpr (kToBelow) {
                         // (row R of this strip is row 0 of the strip below, whose scale starts again at r = 0)
                         const uint32_t down = both(R * ext);
-                        __hip_atomic_store(bout + (uint32_t)(j * kLanes + lane),
-                                           ((unsigned long long)(f - down) << 32) | (H[R - 1] - down),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (odd) {
+                            rowsOut.store(j / 2, lane, StripU4{keepH, keepF, H[R - 1] - down, f - down});
+                        } else {
+                            keepH = H[R - 1] - down;
+                            keepF = f - down;
+                        }
                     }
                     if constexpr (kFromAbove) {
-                        hbPrev = bq[0].x;
-#pragma unroll
-                        for (int x = 0; x < kRowsAhead; ++x) bq[x] = bq[x + 1];
+                        hbPrev = hAbove;
+                        if constexpr (odd) pq0 = pq1;
                     }
                     // ---- answers
                     if constexpr (!kToBelow) {
@@ -2525,6 +2612,11 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                             }
                         }
                     }
+                };
+#pragma unroll 1
+                for (int cp = 0; cp < 4; cp += 2) {
+                    column(std::false_type{}, cp);
+                    column(std::true_type{}, cp + 1);
                 }
                 cur = nxt;
                 shift += 4 * ext;
@@ -2541,15 +2633,21 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
                     sigma -= shift;
                     shift = 0;
                 }
-                if (kToBelow && (((c + 1) & MIOPAL_STRIP_PUBLISH_MASK) == 0 || c + 1 == nChunks)) stripPublish(progOut, c + 1, lane);
+                if (kToBelow && (((c + 1) & MIOPAL_STRIP_PUBLISH_MASK) == 0 || c + 1 == nChunks)) {
+                    timer.start(2);
+                    stripPublish(progOut, c + 1, lane);
+                    timer.stop(2);
+                }
             }
         };
         if (!dead) {
             pace.begin(lane);
+            timer.start(3);
             if (!fromAbove && toBelow) sweep(std::false_type{}, std::true_type{});
             else if (fromAbove && toBelow) sweep(std::true_type{}, std::true_type{});
             else if (fromAbove) sweep(std::true_type{}, std::false_type{});
             // (a single strip is the one-strip kernel's business: launchPairGlobalStrips refuses it)
+            timer.stop(3);
             pace.end(lane);
         }
         if (dead) {
@@ -2580,6 +2678,7 @@ __global__ __launch_bounds__(kPairWaves * kLanes) void interseq_pair_global_stri
             a.score[base + kLanes + lane] = runB;
         }
     }
+    timer.flush(a.stripTiming, lane);
 }
 
 template <int R, bool LOC>
