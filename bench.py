@@ -261,6 +261,8 @@ def main():
                 # HBM bytes per launch from separate rocprofv3 --pmc passes over THIS binary (the
                 # summary carries the sha256 of the libmiopal.so it profiled; null when it differs)
                 "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc else None,
+                "traffic_ratio": round(pmc["hbm_traffic_bytes_per_launch"] / alg_bytes, 3)
+                                 if pmc and pmc.get("hbm_traffic_bytes_per_launch") else None,
                 "traffic_source": pmc["file"] + " (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction of "
                                   "MI355X_MICROARCH.md; library " + pmc["library_sha256"][:16] + ")" if pmc else
                                   "no PMC summary for this build of libmiopal.so (sha256 "
@@ -348,7 +350,7 @@ def pmc_summary(tag="headline"):
     stores the library's sha256 beside the counters)."""
     import glob
     mine = library_sha256()
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{tag}*.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{tag}.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -363,6 +365,7 @@ def pmc_summary(tag="headline"):
             "file": os.path.relpath(path, ROOT),
             "library_sha256": mine,
             "kernel": d.get("kernel"),
+            "kernel_ms": d.get("kernel_ms_unprofiled"),
             "hbm_traffic_bytes_per_launch": d.get("hbm_traffic_bytes_per_launch"),
             "valu_instructions_per_launch": mean("SQ_INSTS_VALU"),
             # LDS: cycles the LDS arrays were busy, the extra cycles of bank conflicts among them, and the
@@ -402,7 +405,56 @@ def leg_roofline(kernel_ms, cells, alg_bytes, routing, pmc_tag, boundary_bytes=N
             # store, one load): real traffic of multi-strip queries, not algorithmic
             "strip_boundary_bytes": boundary_bytes,
             "traffic": pmc["hbm_traffic_bytes_per_launch"] if pmc else None,
+            # counter traffic over algorithmic bytes (1 = nothing read twice; the strips kernels' boundary rows are
+            # real traffic that is not algorithmic: see strip_boundary_bytes)
+            "traffic_ratio": round(pmc["hbm_traffic_bytes_per_launch"] / alg_bytes, 3)
+                             if pmc and pmc.get("hbm_traffic_bytes_per_launch") else None,
+            "traffic_source": pmc["file"] if pmc else None,
             "valu_issue": valu}
+
+
+def full_pipeline_roofline(res, Q, N, L, wall_ms, alg_bytes_whole):
+    """BASELINE configs[2] (`full`): the call is a pipeline of kernels, each with a bound of its own. One entry per
+    kernel: launches per search, time per launch and HBM traffic from the rocprofv3 summaries of THIS build under
+    profiles/ (null when they were taken on another build), algorithmic bytes per launch derived from the result of
+    the search itself (windows, cells and operations of the alignments), the ratio of the two."""
+    end_t, end_q = res["end_t"].astype(np.int64), res["end_q"].astype(np.int64)
+    start_t, start_q = res["start_t"].astype(np.int64), res["start_q"].astype(np.int64)
+    live = (end_t >= 0) & (end_q >= 0)
+    ops = float(res["aln_off"][-1])
+    prefix_residues = float((end_t[live] + 1).sum())                       # the reversed prefixes the start-cell scan reads
+    window_cols = float((end_t[live] - start_t[live] + 1).sum())
+    window_cells = float(((end_t[live] - start_t[live] + 1) * (end_q[live] - start_q[live] + 1)).sum())
+    batches = 4.0
+    stages = [
+        ("end pass (scores + end cells)", "cfg3full_interseq_pair_biased_kernel", 1.0, float(N) * L + 20.0 * N),
+        ("start cells: scan of the reversed prefixes", "cfg3full_perpair_scan_refill_kernel", 1.0, prefix_residues + 28.0 * N),
+        ("directions of the [start..end] rectangles (4 bits a cell)", "cfg3full_perpair_profile_kernel", batches,
+         (window_cols + 0.5 * window_cells + 60.0 * N) / batches),
+        ("walk: operations from the direction bits", "cfg3full_walk_planes_kernel", batches, (2.5 * ops + 60.0 * N) / batches),
+        ("operations compacted into slice order", "cfg3full_gather_ops_kernel", batches, (2.0 * ops + 12.0 * N) / batches),
+        ("operations to pinned host memory, two bits each", "cfg3full_copy_out_packed_kernel", batches, 1.25 * ops / batches),
+    ]
+    kernels = []
+    for what, tag, launches, alg in stages:
+        pmc = pmc_summary(tag)
+        k_ms = pmc.get("kernel_ms") if pmc else None
+        traffic = pmc["hbm_traffic_bytes_per_launch"] if pmc else None
+        achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms else None
+        kernels.append({"stage": what, "kernel": pmc["kernel"] if pmc else tag.split("_", 1)[1],
+                        "launches_per_search": launches, "kernel_ms": round(k_ms, 4) if k_ms else None,
+                        "algorithmic_bytes": round(alg), "achieved": round(achieved, 1) if achieved else None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5) if achieved else None,
+                        "traffic": traffic, "traffic_ratio": round(traffic / alg, 2) if traffic else None,
+                        "wave_cycle_fractions": pmc.get("wave_cycle_fractions") if pmc else None,
+                        "source": pmc["file"] if pmc else None})
+    achieved = alg_bytes_whole / (wall_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "pipeline (see kernels)", "kernel_ms": round(wall_ms, 4), "algorithmic_bytes": alg_bytes_whole,
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+            "note": "kernel_ms / achieved of this block: wall time of the whole call (host-visible results); per kernel below. "
+                    "The direction and scan passes are VALU-issue-bound (14 / 6.5 instructions per cell at 32 bit), the walk by "
+                    "memory latency (one round trip per 64-byte line of direction bits and wavefront)",
+            "kernels": kernels}
 
 
 def strips_of(qlen, sw):
@@ -660,7 +712,7 @@ def extras(db, query, matrix, Q, N, L):
             row[mode] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(cells / dt / 1e9, 1)}
             alg = float(N) * L + (12.0 if mode == "score" else 20.0) * N + qlen + 4 * 24 * 24
             bnd = 16.0 * 64 * (-(-L // 4) * 4) * -(-N // 128) * (strips_of(qlen, True) - 1) if (routing[1] & 15) == 6 else None
-            row[mode]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"q{qlen}_sw" if mode == "score" else None, bnd)
+            row[mode]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"q{qlen}_sw" if mode == "score" else f"q{qlen}_sw_end", bnd)
         longer[f"q{qlen}"] = row
     out["longer_queries_sw"] = longer
     # BASELINE configs[2]: Smith-Waterman with full alignments on the headline database
@@ -669,11 +721,9 @@ def extras(db, query, matrix, Q, N, L):
         ops = int(res["aln_off"][-1])
         cells = float(Q) * N * L
         alg = float(N) * L + 12.0 * N + 16.0 * N + ops + Q + 4 * 24 * 24
-        roof = leg_roofline(dt * 1e3, cells, alg, routing, None,
-                            kernel="pipeline: interseq_pair_biased_kernel<.., true> (end pass), perpair_kernel (start cells, "
-                                   "directions), walk_kernel, gather_ops_kernel; kernel_ms = wall time of the whole call")
         out["cfg3_full"] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(cells / dt / 1e9, 1),
-                            "end_pass_kernel_ms": round(k_ms, 4), "alignment_operations": ops, "roofline": roof}
+                            "end_pass_kernel_ms": round(k_ms, 4), "alignment_operations": ops,
+                            "roofline": full_pipeline_roofline(res, Q, N, L, dt * 1e3, alg)}
         del res
     # BASELINE configs[3] as written: 2000-aa query vs 100k x 2000 PLUS the reference's 35 long targets
     # (1000 ... 35000 residues: the ones that really leave 16 bits), every algorithm, scores
@@ -693,7 +743,7 @@ def extras(db, query, matrix, Q, N, L):
             alg = float(off[-1]) + 12.0 * n_t + 2000 + 4 * 24 * 24
             packed_cols = 2000.0 * 782      # groups of 128 targets x columns, the 33 longest targets aside
             bnd = 16.0 * 64 * packed_cols * (strips_of(2000, algo == "sw") - 1) if (routing[1] & 15) in (6, 7) else None
-            cfg4[algo]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"cfg4_{algo}" if algo in ("nw", "sw") else None, bnd)
+            cfg4[algo]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"cfg4_{algo}", bnd)
         cdb.close()
         out["cfg4_with_tail"] = cfg4
     return out

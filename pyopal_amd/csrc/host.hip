@@ -674,11 +674,82 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
     if (!h) RC_TRY(newHandle(&h, device));
     ResidueSource src;
     src.sequences = (const unsigned char* const*)db;
-    int rc = fillHandle(h.get(), src, std::move(offsets), dbLength, alphabetLength, /*prefetchView=*/true);
-    const auto t1 = std::chrono::steady_clock::now();
-    if (rc == 0)
-        rc = miopalSearchResults(h.get(), query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
-                                 searchType, mode, overflowMethod, 0, dbLength);
+    // Round 4, opt-in (MIOPAL_SEARCH_UNDER_UPLOAD=1): the search UNDER the upload. The lengths are all a packed
+    // view's lists need, so the database is cut into a few contiguous segments (by residues: 30 / 30 / 25 / 15 %,
+    // the last one short); a segment is packed and searched, and its result structs are written, as soon as its
+    // residues are on the device, while the later segments still cross PCIe. Measured (1M x 300, profiles/
+    // r04_search_under_upload.txt): 10.3-10.4 ms per call against 10.5-10.6 with the search behind the upload on one
+    // box, 11.2-11.9 against 11.2-12.2 on another - the host-to-device copies slow down beside the search kernels by
+    // what the overlap saves (upload 7.3 -> 9.2 ms), whatever the number of host threads or CUs left free. Not the
+    // default for that reason; kept, with its test, because the arithmetic is right for a host whose copies do not
+    // share the device with the kernels. Large databases of short targets only (those whose view lists are built
+    // ahead: fillHandle); targets are independent, so the results are those of one search of the whole database
+    // (src/pyopal/_align.py:150-170 cuts the same way over its threads).
+    int64_t longest = 0;
+    if (tuned(Tune::SEARCH_UNDER_UPLOAD)) {
+        const int nSlices = hostThreads((size_t)dbLength, 65536);
+        std::vector<int> sliceMax((size_t)nSlices, 0);
+        parallelSlices(nSlices, [&](int t) {
+            int m = 0;
+            for (int k = (int)((int64_t)dbLength * t / nSlices); k < (int)((int64_t)dbLength * (t + 1) / nSlices); ++k) m = std::max(m, dbSeqLengths[k]);
+            sliceMax[(size_t)t] = m;
+        });
+        for (int m : sliceMax) longest = std::max<int64_t>(longest, m);
+    }
+    const int64_t totalResidues = offsets[(size_t)dbLength];
+    const bool under = tuned(Tune::SEARCH_UNDER_UPLOAD) && dbLength >= 262144 && totalResidues >= (96ll << 20) &&
+                       longest <= 256 + 128 && queryLength > 0 && !tuned(Tune::NO_VIEW_PREFETCH);
+    int rc = 0;
+    auto t1 = t0;
+    if (under) {
+        std::vector<int64_t> bounds{0};
+        for (double share : {0.30, 0.60, 0.85}) {
+            const int64_t goal = (int64_t)(share * (double)totalResidues);
+            int64_t k = std::upper_bound(offsets.begin(), offsets.end(), goal) - offsets.begin() - 1;
+            k = std::min<int64_t>(std::max<int64_t>(k, bounds.back()), dbLength);
+            if (k > bounds.back()) bounds.push_back(k);
+        }
+        if (bounds.back() < dbLength) bounds.push_back(dbLength);
+        std::vector<int64_t> segEndByte;
+        for (size_t k = 1; k < bounds.size(); ++k) segEndByte.push_back(offsets[(size_t)bounds[k]]);
+        UploadProgress progress;
+        bool ready = false;
+        int fillRc = 0;
+        std::string fillError;
+        MiopalDb* const hd = h.get();
+        std::thread filler([&, hd] {
+            // (errors are per thread: this one's message is handed to the caller's)
+            fillRc = guarded([&] { return fillHandle(hd, src, std::move(offsets), dbLength, alphabetLength, true, &bounds, &progress, &ready); });
+            if (fillRc) fillError = g_lastError;
+            progress.finish();
+        });
+        struct Join {
+            std::thread& t;
+            ~Join() { if (t.joinable()) t.join(); }
+        } joinFiller{filler};
+        {
+            std::unique_lock<std::mutex> g(progress.m);
+            progress.cv.wait(g, [&] { return ready || progress.finished; });
+        }
+        for (size_t k = 0; k + 1 < bounds.size() && rc == 0; ++k) {
+            if (!progress.waitFor((size_t)segEndByte[k])) break;   // (the upload ended early: its error is reported below)
+            if (k == 0) (void)hipSetDevice(h->device);
+            rc = miopalSearchResults(hd, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength,
+                                     results + bounds[k], searchType, mode, overflowMethod, bounds[k], bounds[k + 1]);
+        }
+        filler.join();
+        t1 = std::chrono::steady_clock::now();
+        if (fillRc) {
+            g_lastError = fillError;
+            rc = fillRc;
+        }
+    } else {
+        rc = fillHandle(h.get(), src, std::move(offsets), dbLength, alphabetLength, /*prefetchView=*/true);
+        t1 = std::chrono::steady_clock::now();
+        if (rc == 0)
+            rc = miopalSearchResults(h.get(), query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, results,
+                                     searchType, mode, overflowMethod, 0, dbLength);
+    }
     const auto t2 = std::chrono::steady_clock::now();
     if (rc == 0) {
         int64_t keepMb = 4096;

@@ -197,3 +197,43 @@ def test_cache_controls(capi, tuning):
     tuning.setenv("MIOPAL_SPARE_HANDLE_MB", "0")
     np.testing.assert_array_equal(plain_search(capi, q, res, off, B62, 24)["score"][:100], ref)
     assert free0 - torch.cuda.mem_get_info()[0] <= 16 << 20, "nothing is kept with MIOPAL_SPARE_HANDLE_MB=0"
+
+
+def test_search_under_the_upload(capi, tuning):
+    # Round 4 (opt-in, MIOPAL_SEARCH_UNDER_UPLOAD=1: no faster on this pool, host.hip): a large database of short
+    # targets searched in segments while its later segments still cross PCIe. Every score against the AVX2 CPU checker
+    # and against the same call with the search behind the upload (the default); end locations of a sample against
+    # the scalar checker; a bad residue in the LAST segment still fails the call.
+    rng = np.random.default_rng(95)
+    n = 300_000
+    lengths = rng.integers(300, 385, size=n)              # ragged, all within the prefetched views' bound
+    lengths[rng.integers(0, n, size=500)] = 0             # ... and a few empty ones
+    res, off = _data.random_db(rng, lengths)
+    assert off[-1] >= (96 << 20)
+    q = _oracle.encode(_data.README_QUERY)
+    behind = plain_search(capi, q, res, off, B62, 24)
+    tuning.setenv("MIOPAL_SEARCH_UNDER_UPLOAD", "1")
+    under = plain_search(capi, q, res, off, B62, 24)
+    assert under["scoreSet"].all()
+    cpu = _cpu_baseline.CpuDatabase(res, off)
+    want = cpu.search_sw(q, B62, 3, 1, 8)
+    cpu.close()
+    np.testing.assert_array_equal(under["score"], want)
+    np.testing.assert_array_equal(behind["score"], want)
+    # end locations: the whole database again, a sample of every segment against the scalar checker
+    ends = plain_search(capi, q, res, off, B62, 24, mode="end", algo="hw")
+    pick = np.sort(rng.choice(n, size=400, replace=False))
+    sres, soff = _oracle.flatten([res[off[k]:off[k + 1]] for k in pick])
+    ref = _oracle.search(q, sres, soff, B62, 3, 1, "end", "hw")
+    np.testing.assert_array_equal(ends["score"][pick], ref["score"])
+    np.testing.assert_array_equal(ends["endLocationQuery"][pick], ref["end_q"])
+    np.testing.assert_array_equal(ends["endLocationTarget"][pick], ref["end_t"])
+    # a residue outside the alphabet in the last segment: the call fails, whatever the earlier segments returned
+    bad = res.copy()
+    bad[off[-1] - 5] = 24
+    plain_search(capi, q, bad, off, B62, 24, expect_rc=MIOPAL_ERR_BAD_ARGUMENT)
+    assert "out of range" in capi.last_error()
+    # ... and the call after it is clean
+    again = plain_search(capi, q, res, off, B62, 24)
+    np.testing.assert_array_equal(again["score"], want)
+    capi.lib().miopalReleaseCaches()
