@@ -75,6 +75,15 @@ void miopalDbDestroy(MiopalDb* db);
  */
 void miopalReleaseCaches(void);
 
+/*
+ * Searches keep their device workspaces (strip boundaries, direction bits and operations of `full`, staging)
+ * parked on the handle for the next search of whatever thread comes first - up to 64 GB per handle, beyond which a
+ * returning workspace is freed. A process that has run a burst of large `full` searches from many threads and
+ * wants the memory back calls this: every idle workspace of the handle is released (running searches keep
+ * theirs). Returns the device bytes released. No reference counterpart.
+ */
+int64_t miopalDbReleaseWorkspaces(MiopalDb* db);
+
 int64_t miopalDbCount(const MiopalDb* db);
 int64_t miopalDbTotalLength(const MiopalDb* db);
 /* Bytes of HBM held by the mirror (linear copy + packed views). */

@@ -48,7 +48,7 @@ EXPORTS = [
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
     "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalLastRouting", "miopalLastFullRouting", "miopalSearchResults", "miopalReleaseCaches",
-    "miopalSetTuning", "miopalGetTuning", "miopalDbSetOption",
+    "miopalSetTuning", "miopalGetTuning", "miopalDbSetOption", "miopalDbReleaseWorkspaces",
     # test hooks
     "miopalSelfTest", "miopalTestInjectFault", "miopalTestSetLogicalDevices",
 ]
@@ -113,7 +113,7 @@ def lib() -> ctypes.CDLL:
         L.miopalTestSetLogicalDevices.argtypes = [c_int]
         L.miopalDbDestroy.restype = None
         L.miopalDbDestroy.argtypes = [c_vp]
-        for name in ("miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes"):
+        for name in ("miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes", "miopalDbReleaseWorkspaces"):
             getattr(L, name).restype = c_i64
             getattr(L, name).argtypes = [c_vp]
         L.miopalSearch.restype = c_int
@@ -287,6 +287,10 @@ class DeviceDatabase:
 
     def device_bytes(self) -> int:
         return int(lib().miopalDbDeviceBytes(self._h))
+
+    def release_workspaces(self) -> int:
+        """Free the idle per-search workspaces parked on the handle; returns the device bytes released."""
+        return int(lib().miopalDbReleaseWorkspaces(self._h))
 
     def set_option(self, name: str, value: int) -> None:
         """Per-handle option (include/miopal.h, miopalDbSetOption): "reserve_cus", "small_search"."""

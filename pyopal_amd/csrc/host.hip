@@ -390,6 +390,20 @@ void miopalReleaseCaches(void) {
     kits.clear();
 }
 
+int64_t miopalDbReleaseWorkspaces(MiopalDb* db) {
+    if (!db) return 0;
+    std::vector<std::unique_ptr<Workspace>> idle;
+    {
+        std::lock_guard<std::mutex> g(db->wsMutex);
+        idle.swap(db->ownedFree);
+    }
+    int64_t bytes = 0;
+    for (const auto& w : idle) bytes += (int64_t)w->bytes();
+    (void)hipSetDevice(db->device);
+    idle.clear();   // (workspaces in use by running searches are not in the list: they come back and are kept)
+    return bytes;
+}
+
 int64_t miopalDbCount(const MiopalDb* db) { return db ? db->count : 0; }
 int64_t miopalDbTotalLength(const MiopalDb* db) { return db ? db->total : 0; }
 int64_t miopalDbDeviceBytes(const MiopalDb* db) {

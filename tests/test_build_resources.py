@@ -59,6 +59,9 @@ def test_spills_of_the_strips_kernels_stay_out_of_the_column_loops():
                          timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.count("column blocks") >= 6, out.stdout
+    # ... and the ISA the hand-over between strips relies on (common.h: outside the LLVM memory model): boundary rows
+    # as 16-byte sc1 buffer accesses, progress counters stored behind a drained vmcnt
+    assert out.stdout.count("hand-over:") >= 6 and "(0 without sc1)" in out.stdout, out.stdout
 
 
 def test_pair_table_kernels_keep_three_wavefronts_per_simd():

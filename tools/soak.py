@@ -39,3 +39,9 @@ print(f"1800 mixed searches on 4 threads in {time.time()-t0:.1f} s; errors={len(
       f"device memory held after run: {(free0-free1)/2**20:.0f} MiB more than after warm-up; "
       f"mirror bytes {db.device_bytes()/2**20:.0f} MiB")
 assert not errors, errors[:5]
+released = db.release_workspaces()
+free2 = torch.cuda.mem_get_info()[0]
+print(f"miopalDbReleaseWorkspaces: {released/2**20:.0f} MiB of idle workspaces released; device memory held now: "
+      f"{(free0-free2)/2**20:.0f} MiB more than after warm-up")
+assert db.search(queries[0], m, 3, 1, "full", "sw")["score"].tolist() == ref[(0, "sw")].tolist()
+
