@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES 
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $p/pmc_sq2 --output-format csv -- $w > $p/pmc_sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $p/pmc_fetch --output-format csv -- $w > $p/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $p/pmc_write --output-format csv -- $w > $p/pmc_write.log 2>&1
-for needle in ${needles//,/ }; do
+for needle in ${needles//,/ }; do   # (a needle may carry template arguments: perpair_profile_kernel<4>)
     kms=$(python3 - "$out/${tag}_${name}_kernel_stats.csv" "$needle" <<'EOF'
 import csv, sys
 best = None
@@ -34,7 +34,7 @@ print((best or 0) / 1e6)
 EOF
 )
     if [ "$kms" = "0.0" ]; then echo "kernel $needle not in the trace"; continue; fi
-    suffix=$name; [ "$needles" != "$needle" ] && suffix=${name}_$needle
+    suffix=$name; [ "$needles" != "$needle" ] && suffix=${name}_$(echo "$needle" | tr -d '>' | tr '<' '_')
     PMC_COMMAND="rocprofv3 --kernel-trace --pmc <counters> --output-format csv -- python3 tools/pmc_workload.py $* (separate passes: SQ issue + GRBM, SQ waits / LDS, FETCH_SIZE, WRITE_SIZE)" \
     PMC_CELLS=$(grep -o "cells=[0-9]*" $p/trace.log | head -1 | cut -d= -f2) \
     python3 $root/tools/summarize_pmc.py $out/${tag}_pmc_$suffix.json $needle $kms $p/pmc_sq $p/pmc_sq2 $p/pmc_fetch $p/pmc_write
