@@ -715,6 +715,12 @@ def extras(db, query, matrix, Q, N, L):
             row[mode]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"q{qlen}_sw" if mode == "score" else f"q{qlen}_sw_end", bnd)
         longer[f"q{qlen}"] = row
     out["longer_queries_sw"] = longer
+    # the headline search with end locations (row keys in the low bits of every value: no row scan)
+    dt, k_ms, routing, _ = timed_leg(db, query, "end", "sw", 5)
+    cells = float(Q) * N * L
+    out["cfg2_end"] = {"ms": round(dt * 1e3, 3), "host_results_gcups": round(cells / dt / 1e9, 1),
+                       "roofline": leg_roofline(k_ms, cells, float(N) * L + 20.0 * N + Q + 4 * 24 * 24, routing, "cfg2_end",
+                                                kernel=f"interseq_pair_biased_kernel<{max(2, (Q + 1) // 2 * 2)}, true>")}
     # BASELINE configs[2]: Smith-Waterman with full alignments on the headline database
     if (N, L) == (1_000_000, 300):
         dt, k_ms, routing, res = timed_leg(db, query, "full", "sw", 3)
