@@ -71,9 +71,10 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
-    for line in child.stdout:          # rank 0's line (and anything else the ranks print), as it comes
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in child.stdout:          # rank 0's JSON line to stdout; whatever else the ranks print (gloo's
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr   # connection notes, ...) to stderr
+        out.write(line)
+        out.flush()
     return child.wait()
 
 
