@@ -794,11 +794,12 @@ def cpu_baseline(query, residues, offsets, matrix, Q, N, L, gpu_scores):
     and every core the process may use (one thread per physical core)."""
     model, physical, logical, usable = host_cpu()
     # (ranks started by torch.distributed.run inherit OMP_NUM_THREADS=1: this leg runs after the group has ended,
-    # on rank 0 alone, and takes the cores the process may use - the OpenMP runtime reads the variable when it loads)
-    if os.environ.get("OMP_NUM_THREADS") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        os.environ["OMP_NUM_THREADS"] = str(max(1, min(physical, usable)))
+    # on rank 0 alone, and takes the cores the process may use)
     import _cpu_baseline
-    threads = max(1, min(physical, usable, _cpu_baseline.max_threads()))
+    limit = _cpu_baseline.max_threads()
+    if os.environ.get("OMP_NUM_THREADS") == "1" and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        limit = usable   # (the search sets its thread count itself: omp_set_num_threads)
+    threads = max(1, min(physical, usable, limit))
     n = N  # the whole workload: an all-core pass takes tens of milliseconds, a one-thread pass ~1 s
     cdb = _cpu_baseline.CpuDatabase(residues[:offsets[n]], offsets[:n + 1], 24)
 
