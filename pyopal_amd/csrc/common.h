@@ -117,6 +117,7 @@ struct IntraseqArgs {
     int fatBlocks;            // workgroups of 16 wavefronts (beside a persistent packed launch) instead of 4
     int stripWaitCap;         // polls before a unit gives up on the strip above; 0 = the default
     int faultUnit1;           // test hook: unit (this - 1) publishes nothing; 0 = none
+    int wide;                 // every job is a pair of one strip without the stop rule: intraseq_wide_kernel (two columns a step)
 };
 
 struct WalkArgs {

@@ -237,6 +237,147 @@ __global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_kernel(Intras
     }
 }
 
+// ---- pairs of one strip, two columns a step (round 4) ------------------------------------------
+// intraseq_kernel advances one anti-diagonal a step: ~33 instructions on ONE wavefront, a chain of L + Q steps of
+// ~350 cycles (0.15 us) that nothing overlaps - the 8000-residue target of a log-normal database is 1.2 ms on the
+// side stream, whatever the packed launch beside it does, and the pace of NW / OV searches of such databases
+// (profiles/r04_skewed_skip_shares.txt). A step is bound by instruction issue, not by the depth of its
+// dependences: the shuffles that hand a row's values to the row below, the residue stage, the loop - paid per
+// step whatever the step computes. Here a lane computes TWO columns of its row per step (lane i, step k: columns
+// 2 (k - i) and 2 (k - i) + 1; what the row above computed one step earlier), so a pair is a chain of L / 2 + Q
+// steps of ~1.4 x the work: scores (and, with LOC, end locations: the same first maximum in column-major order)
+// of forward or reversed jobs of one strip, every border rule and answer region, no stop rule, no direction
+// bytes - the side jobs of one-strip searches and small searches.
+template <bool LOC>
+__global__ __launch_bounds__(kJobsPerBlock * kLanes) void intraseq_wide_kernel(IntraseqArgs a) {
+    __shared__ int smat[kMaxAlphabet * kMatStride];
+    const int A = a.alphabet;
+    for (int idx = threadIdx.x; idx < A * A; idx += blockDim.x)
+        smat[(idx / A) * kMatStride + (idx % A)] = a.matrix[idx];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int jobIdx = blockIdx.x * kJobsPerBlock + wave;
+    if (jobIdx >= a.nJobs) return;  // wave-uniform, after the only barrier
+    const PairJob job = a.jobs[jobIdx];
+    const int Q = job.qLen, L = job.tLen;   // Q <= 64 (launchIntraseq)
+    if (a.raisePriority) __builtin_amdgcn_s_setprio(3);
+    const bool topGap = job.rules & 1, leftGap = job.rules & 2, floor0 = job.rules & 4;
+    const int hFloor = floor0 ? 0 : INT32_MIN;
+    const int region = (job.rules >> 4) & 3;
+    const int open = a.gapOpen, ext = a.gapExt;
+    int best = floor0 ? 0 : INT32_MIN;
+    int bi = -1, bj = -1;
+    if (Q > 0 && L > 0) {
+        const uint8_t* tptr = a.residues + job.tOff;
+        const int i = lane;
+        const bool rowActive = i < Q;
+        const int qres = rowActive ? a.query[job.qOff + (int64_t)i * job.qStep] : 0;
+        const int* srow = smat + qres * kMatStride;
+        int hLeft = leftGap ? borderGap(i, open, ext) : 0;                               // H[i][-1]
+        int eLeft = kNegInf;
+        int hDiag = (i == 0) ? 0 : (leftGap ? borderGap(i - 1, open, ext) : 0);          // H[i-1][-1]
+        int hA = 0, fA = kNegInf, hB = 0, fB = kNegInf;   // H, F of the step's two columns, as the row below reads them
+        const bool rowIsLast = i == Q - 1;
+        const bool candAlways = rowActive && (region == kAllCells || (rowIsLast && region != kLastCell));
+        const bool candOnLastCol = rowActive && (region == kLastRowCol || (region == kLastCell && rowIsLast));
+        constexpr int kShr1 = 0x138, kRol1 = 0x134;
+        auto pairAt = [&](int p) -> int {   // residues of columns 2 p and 2 p + 1, one byte each (0 beyond the target)
+            const int j = 2 * p;
+            const int r0 = j < L ? (int)tptr[(int64_t)j * job.tStep] : 0;
+            const int r1 = j + 1 < L ? (int)tptr[(int64_t)(j + 1) * job.tStep] : 0;
+            return r0 | (r1 << 8);
+        };
+        int tres = lane == 0 ? pairAt(0) : 0;   // the residue pair of step 0 (lane 0 only)
+        int scA = srow[tres & 0xff], scB = srow[(tres >> 8) & 0xff];
+        int tbuf = 0;
+        // top border of the two columns of step k, either way of paying for it (common.h borderGap)
+        int topOne = open, topMany = open;
+        const int nSteps = (L + 1) / 2 + Q - 1;   // wave-uniform
+        auto candidate = [&](int h, int j) {
+            const bool inside = (unsigned)j < (unsigned)L;
+            const bool cand = candAlways | (candOnLastCol & (j == L - 1));
+            if constexpr (LOC) {
+                const bool improves = (h > best) | ((h == best) & (j < bj));
+                const bool take = inside & cand & improves;
+                best = take ? h : best;
+                bi = take ? i : bi;
+                bj = take ? j : bj;
+            } else {
+                best = max(best, (inside & cand) ? h : INT32_MIN);
+            }
+        };
+        for (int k0 = 0; k0 < nSteps; k0 += kLanes) {
+            tbuf = pairAt(k0 + 1 + lane);   // residue pairs of steps k0 + 1 .. k0 + 64
+            const int kEnd = min(k0 + kLanes, nSteps);
+            for (int k = k0; k < kEnd; ++k) {
+                // residue stage of step k + 1
+                const int tnext = __builtin_amdgcn_update_dpp(tbuf, tres, kShr1, 0xf, 0xf, false);
+                tbuf = __builtin_amdgcn_update_dpp(tbuf, tbuf, kRol1, 0xf, 0xf, false);
+                const int scNextA = srow[tnext & 0xff], scNextB = srow[(tnext >> 8) & 0xff];
+                tres = tnext;
+                // the row above (lane 0: the top border of columns 2 k and 2 k + 1)
+                const int hTop0 = topGap ? -min(topOne, topMany) : 0;
+                const int hTop1 = topGap ? -min(topOne + ext, topMany + open) : 0;
+                topOne += 2 * ext;
+                topMany += 2 * open;
+                const int hUp0 = __builtin_amdgcn_update_dpp(hTop0, hA, kShr1, 0xf, 0xf, false);
+                const int fUp0 = __builtin_amdgcn_update_dpp(kNegInf, fA, kShr1, 0xf, 0xf, false);
+                const int hUp1 = __builtin_amdgcn_update_dpp(hTop1, hB, kShr1, 0xf, 0xf, false);
+                const int fUp1 = __builtin_amdgcn_update_dpp(kNegInf, fB, kShr1, 0xf, 0xf, false);
+                const int j0 = 2 * (k - lane);
+                // first column of the step
+                const int e0 = max(hLeft - open, eLeft - ext);
+                const int f0 = max(hUp0 - open, fUp0 - ext);
+                const int h0 = max(max(hDiag + scA, hFloor), max(e0, f0));
+                // ... and the second, one cell to the right
+                const int e1 = max(h0 - open, e0 - ext);
+                const int f1 = max(hUp1 - open, fUp1 - ext);
+                const int h1 = max(max(hUp0 + scB, hFloor), max(e1, f1));
+                hA = h0; fA = f0; hB = h1; fB = f1;
+                // a lane that has not reached its first column keeps its borders
+                const bool started = j0 >= 0;
+                hLeft = started ? h1 : hLeft;
+                eLeft = started ? e1 : eLeft;
+                hDiag = started ? hUp1 : hDiag;
+                candidate(h0, j0);
+                candidate(h1, j0 + 1);
+                scA = scNextA;
+                scB = scNextB;
+            }
+        }
+        // wave reduction: highest score, then smallest column, then smallest row
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int os = __shfl_xor(best, off), oi = __shfl_xor(bi, off), oj = __shfl_xor(bj, off);
+            if constexpr (LOC) {
+                const bool mineEmpty = bi < 0, otherEmpty = oi < 0;
+                bool take;
+                if (otherEmpty) take = false;
+                else if (mineEmpty) take = !floor0 || os > best;
+                else take = better(os, oj, oi, best, bj, bi);
+                if (take) {
+                    best = os;
+                    bi = oi;
+                    bj = oj;
+                }
+            } else {
+                best = max(best, os);
+            }
+        }
+    } else if (!floor0) {
+        // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+        best = 0;
+        if (Q > 0) best = leftGap ? borderGap(Q - 1, open, ext) : 0;
+        if (L > 0) best = topGap ? borderGap(L - 1, open, ext) : 0;
+    }
+    if (lane == 0) {
+        a.score[job.out] = best;
+        if (LOC && a.endI) a.endI[job.out] = bi;
+        if (LOC && a.endJ) a.endJ[job.out] = bj;
+    }
+}
+
 // ---- long pairs, strip-parallel --------------------------------------------------------------
 // intraseq_kernel sweeps the strips of a pair one after the other: a chain of strips x (L + 63)
 // dependent steps of ~600 cycles each, however many wavefronts the chip has. The 35 000-residue
@@ -1032,6 +1173,14 @@ hipError_t launchReverseJobs(int n, const int32_t* score, const int32_t* endQ, c
 hipError_t launchIntraseq(const IntraseqArgs& a, bool trace, hipStream_t stream) {
     if (a.nJobs <= 0) return hipSuccess;
     const int blocks = (a.nJobs + kJobsPerBlock - 1) / kJobsPerBlock;
+    if (a.wide && !trace && !a.headWaves) {
+        // (the host has checked its jobs: one strip each, no stop rule)
+        if (a.endI || a.endJ)
+            hipLaunchKernelGGL((intraseq_wide_kernel<true>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+        else
+            hipLaunchKernelGGL((intraseq_wide_kernel<false>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
+        return hipGetLastError();
+    }
     if (trace)
         hipLaunchKernelGGL((intraseq_kernel<true>), dim3(blocks), dim3(kJobsPerBlock * kLanes), 0, stream, a);
     else
