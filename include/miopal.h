@@ -118,6 +118,26 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
                      unsigned char** operations, int64_t* operationOffsets);
 
 /*
+ * miopalSearchFlat with the operations written into a buffer the caller lends.
+ * In: *operations is NULL, or a malloc'ed buffer of *operationsCapacity bytes
+ * (the one an earlier call returned, its contents no longer needed). Out:
+ * *operations holds the operations and *operationsCapacity its size in bytes.
+ * When the lent buffer is large enough the SAME pointer comes back, written in
+ * place: its pages are resident already, where a fresh buffer of a million
+ * alignments is 67-360 MB of first-touch page faults per search (and as much to
+ * unmap when it is freed). When it is too small the call returns a buffer of its
+ * own and leaves the lent one untouched - still the caller's, to free or to keep.
+ * On error both values are as they were. Same per-result `alignment` semantics
+ * as above (src/pyopal/opal.pxd:24-32).
+ */
+int miopalSearchFlatInto(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen,
+                         int gapExt, const int* scoreMatrix, int alphabetLength, int searchType,
+                         int mode, int64_t start, int64_t end, int* score, int* endTarget,
+                         int* endQuery, int* startTarget, int* startQuery,
+                         unsigned char** operations, int64_t* operationsCapacity,
+                         int64_t* operationOffsets);
+
+/*
  * Score-only search whose int32 results stay in HBM: `deviceScores` is a
  * device pointer with end - start entries (database order), `stream` a
  * hipStream_t (NULL = the null stream). The call only enqueues work; the

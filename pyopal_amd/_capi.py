@@ -46,7 +46,7 @@ EXPORTS = [
     # miopal.h
     "miopalDeviceCount", "miopalLastError", "miopalDbCreate", "miopalDbCreateFlat", "miopalDbCreateSubset",
     "miopalDbDestroy", "miopalDbCount", "miopalDbTotalLength", "miopalDbDeviceBytes",
-    "miopalSearch", "miopalSearchFlat", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
+    "miopalSearch", "miopalSearchFlat", "miopalSearchFlatInto", "miopalSearchDeviceScores", "miopalSetProfiling", "miopalLastKernelTime",
     "miopalLastRouting", "miopalLastFullRouting", "miopalSearchResults", "miopalReleaseCaches",
     "miopalSetTuning", "miopalGetTuning", "miopalDbSetOption", "miopalDbReleaseWorkspaces",
     # test hooks
@@ -123,6 +123,10 @@ def lib() -> ctypes.CDLL:
         L.miopalSearchFlat.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
                                        c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
                                        ctypes.POINTER(c_vp), c_vp]
+        L.miopalSearchFlatInto.restype = c_int
+        L.miopalSearchFlatInto.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int,
+                                           c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           ctypes.POINTER(c_vp), ctypes.POINTER(c_i64), c_vp]
         L.miopalSearchDeviceScores.restype = c_int
         L.miopalSearchDeviceScores.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int,
                                                c_i64, c_i64, c_vp, c_vp]
@@ -206,13 +210,27 @@ def _ptr(a: typing.Optional[np.ndarray]):
 class _MallocBytes:
     """Owner of a buffer returned by the C ABI; numpy arrays made from it keep it alive."""
 
-    def __init__(self, address: int, size: int):
+    def __init__(self, address: int, size: int, capacity: int = 0):
         self._address = address
+        self._capacity = max(capacity, size)
         self.__array_interface__ = {"data": (address, False), "shape": (size,), "typestr": "|u1",
                                     "version": 3}
 
+    def view(self, size: int) -> "_MallocView":
+        return _MallocView(self, size)
+
     def __del__(self):
-        _libc.free(ctypes.c_void_p(self._address))
+        if _libc is not None:   # (gone at interpreter shutdown: the process is about to return its memory anyway)
+            _libc.free(ctypes.c_void_p(self._address))
+
+
+class _MallocView:
+    """The first ``size`` bytes of a _MallocBytes buffer that was written again (``reuse=``)."""
+
+    def __init__(self, owner: _MallocBytes, size: int):
+        self._owner = owner
+        self.__array_interface__ = {"data": (owner._address, False), "shape": (size,), "typestr": "|u1",
+                                    "version": 3}
 
 
 class _LazyAlignments:
@@ -305,9 +323,12 @@ class DeviceDatabase:
         int32 array of end - start entries to receive the scores (a caller that re-uses its result
         array; when it is pinned, device-visible host memory the kernel writes into it directly).
         ``reuse``: the result of an earlier search of the same slice and search type whose per-target
-        arrays (scores, locations, operation offsets) are written again instead of fresh ones - the
-        earlier result's arrays then hold the new values (a million targets: 36 MB of pages that need
-        not be faulted in again, 1.3 ms of a 11.5-ms `full` search)."""
+        arrays (scores, locations, operation offsets) and operations buffer are written again instead of
+        fresh ones - the earlier result's arrays then hold the new values (a million targets: 36 MB of
+        per-target pages and 67-360 MB of operations that need not be faulted in again, nor unmapped when
+        the earlier result goes: 1.3 ms of a 11.5-ms `full` search for the arrays, 17 of 113 ms for the
+        operations of a 300-residue query). An operations buffer that is too small stays with the earlier
+        result, untouched."""
         end = self.count if end is None else min(end, self.count)
         n = max(end - start, 0)
         q = np.ascontiguousarray(query, dtype=np.uint8)
@@ -329,6 +350,13 @@ class DeviceDatabase:
         out = {"score": score_out if score_out is not None else array("score", n, np.int32)}
         et = eq = s_t = s_q = aoff = None
         ops_ptr = ctypes.c_void_p()
+        ops_cap = ctypes.c_int64(0)
+        lent = reuse.get("_ops_owner") if reuse and st == 2 else None
+        if isinstance(lent, _MallocBytes):
+            ops_ptr = ctypes.c_void_p(lent._address)
+            ops_cap = ctypes.c_int64(lent._capacity)
+        else:
+            lent = None
         if st >= 1:
             et = array("end_t", n, np.int32)
             eq = array("end_q", n, np.int32)
@@ -336,22 +364,29 @@ class DeviceDatabase:
             s_t = array("start_t", n, np.int32)
             s_q = array("start_q", n, np.int32)
             aoff = array("aln_off", n + 1, np.int64, zeros=True)
-        rc = lib().miopalSearchFlat(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
-                                    self.alphabet_length, st, MODE[algorithm], start, end,
-                                    _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),
-                                    ctypes.byref(ops_ptr), _ptr(aoff))
+        rc = lib().miopalSearchFlatInto(self._h, _ptr(q), len(q), gap_open, gap_extend, _ptr(S),
+                                        self.alphabet_length, st, MODE[algorithm], start, end,
+                                        _ptr(out["score"]), _ptr(et), _ptr(eq), _ptr(s_t), _ptr(s_q),
+                                        ctypes.byref(ops_ptr), ctypes.byref(ops_cap), _ptr(aoff))
         raise_for(rc)
         if st >= 1:
             out.update(end_t=et, end_q=eq)
         if st == 2:
             total = int(aoff[-1]) if n else 0
-            if ops_ptr.value:
+            owner = None
+            if lent is not None and ops_ptr.value == lent._address:
+                # written in place: the earlier result's buffer, owned as before (and seen through its arrays too)
+                owner = lent
+                owner._capacity = max(owner._capacity, int(ops_cap.value))
+                flat = np.asarray(owner.view(total))
+            elif ops_ptr.value:
                 # the array takes the malloc'ed buffer over (freed with the array) - no copy
-                flat = np.asarray(_MallocBytes(ops_ptr.value, total))
+                owner = _MallocBytes(ops_ptr.value, total, int(ops_cap.value))
+                flat = np.asarray(owner)
             else:
                 flat = np.zeros(0, dtype=np.uint8)
             out.update(start_t=s_t, start_q=s_q, aln_flat=flat, aln_off=aoff,
-                       aln=_LazyAlignments(flat, aoff))
+                       aln=_LazyAlignments(flat, aoff), _ops_owner=owner)
         return out
 
     def search_device_scores(self, query: np.ndarray, matrix: np.ndarray, device_ptr: int,

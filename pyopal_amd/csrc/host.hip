@@ -184,13 +184,33 @@ constexpr size_t kMaxCachedViews = 64;                 // packed views per handl
 struct HostBytes {
     uint8_t* data = nullptr;
     size_t size = 0, cap = 0;
+    // `data` is a buffer the caller of the C ABI lent for this search (miopalSearchFlatInto): written in
+    // place when it is large enough, never freed or moved here - a search that needs more leaves it alone
+    // and returns a buffer of its own
+    bool lent = false;
     HostBytes() = default;
     HostBytes(const HostBytes&) = delete;
     HostBytes& operator=(const HostBytes&) = delete;
-    ~HostBytes() { free(data); }
+    ~HostBytes() {
+        if (!lent) free(data);
+    }
+    void lend(uint8_t* buffer, size_t capacity) {
+        if (!buffer || capacity == 0) return;
+        data = buffer;
+        cap = capacity;
+        size = 0;
+        lent = true;
+    }
     bool reserve(size_t want) {
         if (want <= cap) return true;
         want = std::max(want, cap + cap / 2);
+        uint8_t* keep = nullptr;   // a lent buffer that is too small: its contents move, it stays the caller's
+        if (lent) {
+            keep = data;
+            data = nullptr;
+            lent = false;
+            want += want / 4;   // (the next search of this kind fits the buffer it gets back)
+        }
         const bool hugePages = !tuned(Tune::NO_HUGEPAGE);
         if (!data && want >= (8u << 20) && hugePages) {
             // a large result buffer is written once, front to back: ask for huge pages so that
@@ -199,12 +219,20 @@ struct HostBytes {
             if (posix_memalign(&p, 2u << 20, want) == 0) {
                 madvise(p, want, MADV_HUGEPAGE);
                 data = (uint8_t*)p;
+                if (keep && size) memcpy(data, keep, size);
                 cap = want;
                 return true;
             }
         }
         uint8_t* p = (uint8_t*)realloc(data, want);
-        if (!p) return false;
+        if (!p) {
+            if (keep) {   // (as before the call)
+                data = keep;
+                lent = true;
+            }
+            return false;
+        }
+        if (keep && size) memcpy(p, keep, size);
         data = p;
         cap = want;
         return true;
@@ -220,10 +248,13 @@ struct HostBytes {
         size += n;
         return true;
     }
-    uint8_t* release() {
+    // the storage leaves for the caller (a lent buffer goes back the same way); `capacity`: its size in bytes
+    uint8_t* release(size_t* capacity = nullptr) {
         uint8_t* p = data;
+        if (capacity) *capacity = cap;
         data = nullptr;
         size = cap = 0;
+        lent = false;
         return p;
     }
 };
@@ -555,6 +586,29 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
     if (full && end > start) {
         if (!ops.data && !ops.resize(0)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
         *operations = ops.release();
+    }
+    return 0;
+    });
+}
+
+int miopalSearchFlatInto(MiopalDb* db, const unsigned char* query, int queryLength, int gapOpen, int gapExt,
+                         const int* scoreMatrix, int alphabetLength, int searchType, int mode, int64_t start,
+                         int64_t end, int* score, int* endTarget, int* endQuery, int* startTarget,
+                         int* startQuery, unsigned char** operations, int64_t* operationsCapacity,
+                         int64_t* operationOffsets) {
+    return guarded([&]() -> int {
+    HostBytes ops;
+    const bool full = searchType == OPAL_SEARCH_ALIGNMENT;
+    if (full && (!operations || !operationsCapacity)) return fail(MIOPAL_ERR_BAD_ARGUMENT, "null alignment outputs");
+    if (full && *operations && *operationsCapacity > 0) ops.lend(*operations, (size_t)*operationsCapacity);
+    RC_TRY(searchImpl(db, query, queryLength, gapOpen, gapExt, scoreMatrix, alphabetLength, searchType, mode,
+                      start, end, score, endTarget, endQuery, startTarget, startQuery, nullptr, nullptr,
+                      full ? &ops : nullptr, full ? operationOffsets : nullptr));
+    if (full && end > start) {
+        if (!ops.data && !ops.resize(0)) return fail(MIOPAL_ERR_INTERNAL, "out of host memory");
+        size_t capacity = 0;
+        *operations = ops.release(&capacity);
+        *operationsCapacity = (int64_t)capacity;
     }
     return 0;
     });

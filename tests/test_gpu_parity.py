@@ -86,6 +86,27 @@ def test_results_written_into_the_arrays_of_an_earlier_search(capi):
             # arrays of another shape or type are not taken
             other = db.search(q2, B62, 3, 1, mode, "sw", 0, 100, reuse=second)
             assert other["score"] is not second["score"] and len(other["score"]) == 100
+        # the operations buffer (miopalSearchFlatInto): written in place when it is large enough ...
+        q3 = _data.random_protein(rng, 70)
+        a = db.search(q3, B62, 3, 1, "full", "sw")
+        a["aln_flat"][:] = 7   # (whatever the earlier result held is gone)
+        b = db.search(q3, B62, 3, 1, "full", "sw", reuse=a)
+        assert b["_ops_owner"] is a["_ops_owner"]
+        compare(b, _oracle.search(q3, res, off, B62, 3, 1, "full", "sw"), "full", "operations in place")
+        part = db.search(q3, B62, 3, 1, "full", "sw", 10, 60, reuse=b)   # (fewer targets: the same buffer, a shorter view of it)
+        assert part["_ops_owner"] is b["_ops_owner"]
+        compare(part, _oracle.search(q3, res[off[10]:off[60]], off[10:61] - off[10], B62, 3, 1, "full", "sw"), "full", "a slice in place")
+        # ... and left alone, with its owner, when it is too small
+        small = db.search(q3, B62, 3, 1, "full", "sw", 0, 50)
+        before = small["aln_flat"].copy()
+        big = db.search(_data.random_protein(rng, 300), B62, 3, 1, "full", "sw", reuse=small)
+        assert big["_ops_owner"] is not small["_ops_owner"]
+        assert np.array_equal(small["aln_flat"], before)
+        again = db.search(q3, B62, 3, 1, "full", "sw", reuse=big)
+        assert again["_ops_owner"] is big["_ops_owner"]
+        compare(again, _oracle.search(q3, res, off, B62, 3, 1, "full", "sw"), "full", "after a larger search")
+        empty = db.search(q3, B62, 3, 1, "full", "sw", 5, 5, reuse=again)
+        assert len(empty["aln_flat"]) == 0 and len(empty["score"]) == 0
     finally:
         db.close()
 

@@ -1,0 +1,20 @@
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _data
+from pyopal_amd import _capi
+from pyopal_amd.matrices import ScoringMatrix
+m = np.array(ScoringMatrix.from_name("BLOSUM62").int_array(), dtype=np.int32)
+res, off = _data.random_db(np.random.default_rng(1), np.full(1_000_000, 300))
+q = _data.random_protein(np.random.default_rng(4), 300)
+db = _capi.DeviceDatabase(res, off, 24)
+r = None
+for _ in range(2):
+    r = db.search(q, m, 3, 1, "full", "sw", reuse=r)
+ts = []
+for _ in range(5):
+    t0 = time.perf_counter(); r = db.search(q, m, 3, 1, "full", "sw", reuse=r); ts.append(time.perf_counter() - t0)
+print("Q=300 full ms:", " ".join(f"{t*1e3:.1f}" for t in ts), "ops", int(r["aln_off"][-1]), flush=True)
+with _capi.tuning(PHASE_TIMING="1"):
+    r = db.search(q, m, 3, 1, "full", "sw", reuse=r)
