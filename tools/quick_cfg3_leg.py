@@ -17,8 +17,10 @@ def where():
     node = [os.path.basename(p) for p in glob.glob(f"/sys/devices/system/cpu/cpu{cpu}/node*")]
     return f"cpu {cpu} {node}"
 rng = np.random.default_rng(1)
-res, off = _data.random_db(rng, np.full(1_000_000, 300))
+res, off = _data.random_db(rng, np.full(int(os.environ.get("N", 1_000_000)), 300))
 q = _data.encode(_data.README_QUERY)
+if os.environ.get("RANDOMQ"):
+    q = _data.random_protein(np.random.default_rng(int(os.environ["RANDOMQ"])), 53)
 db = _capi.DeviceDatabase(res, off, 24)
 print(f"database created on {where()}", flush=True)
 SUSTAIN = os.environ.get("SUSTAIN", "")   # (what bench.py runs before its cfg3 leg: "s" six seconds of the headline search, "d" another database, "q" a longer query)
