@@ -714,6 +714,22 @@ def extras(db, query, matrix, Q, N, L):
             alg = float(N) * L + (12.0 if mode == "score" else 20.0) * N + qlen + 4 * 24 * 24
             bnd = 16.0 * 64 * (-(-L // 4) * 4) * -(-N // 128) * (strips_of(qlen, True) - 1) if (routing[1] & 15) == 6 else None
             row[mode]["roofline"] = leg_roofline(k_ms, cells, alg, routing, f"q{qlen}_sw" if mode == "score" else f"q{qlen}_sw_end", bnd)
+        if qlen == 300 and (N, L) == (1_000_000, 300):
+            # full alignments with a query of five strips of rows (the earlier result lent back, as in cfg3_full)
+            dt, k_ms, routing, res = timed_leg(db, q, "full", "sw", 3)
+            stages = []
+            for what, tag, launches in (("end pass", "q300full_interseq_pair_strips_kernel", 1),
+                                        ("start cells: scan of the reversed prefixes", "q300full_perpair_profile_kernel_3", 1),
+                                        ("directions (4 bits a cell)", "q300full_perpair_profile_kernel_4", 8),
+                                        ("walk", "q300full_walk_planes_kernel", 8)):
+                pmc = pmc_summary(tag)
+                stages.append({"stage": what, "launches_per_search": launches,
+                               "kernel_ms": round(pmc["kernel_ms"], 3) if pmc and pmc.get("kernel_ms") else None,
+                               "source": pmc["file"] if pmc else None})
+            row["full"] = {"ms": round(dt * 1e3, 2), "host_results_gcups": round(float(qlen) * N * L / dt / 1e9, 1),
+                           "alignment_operations": int(res["aln_off"][-1]), "kernels": stages,
+                           "note": "VALU-issue-bound passes at 32 bit (8.1 / 15 instructions per cell): DESIGN.md section 7"}
+            del res
         longer[f"q{qlen}"] = row
     out["longer_queries_sw"] = longer
     # the headline search with end locations (row keys in the low bits of every value: no row scan)
