@@ -224,6 +224,32 @@ def test_alternative_full_mode_paths(capi, tuning, switch):
             compare(gpu, ref, "full", f"{switch} {algo} Q={qlen}")
 
 
+def test_full_in_batches_with_and_without_the_side_stream_copies(capi, tuning):
+    """A `full` search of enough targets for several batches (host_full.inc: the per-target arrays leave on the
+    side stream batch by batch and are copied out and prefix-summed between batches) against the same search
+    with everything sent behind the last batch (`MIOPAL_NO_SIDE_COPIES`), and the head of it against the checker."""
+    rng = np.random.default_rng(77)
+    n = 4 * 65536 + 1000
+    res, off = _data.random_db(rng, rng.integers(20, 90, size=n))
+    q = _data.random_protein(rng, 40)
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        for algo in ("sw", "hw"):
+            a = db.search(q, B62, 3, 1, "full", algo)
+            tuning.setenv("MIOPAL_NO_SIDE_COPIES", "1")
+            b = db.search(q, B62, 3, 1, "full", algo)
+            tuning.delenv("MIOPAL_NO_SIDE_COPIES")
+            c = db.search(q, B62, 3, 1, "full", algo, reuse=a)   # (and into the arrays and the operations buffer of `a`)
+            for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
+                np.testing.assert_array_equal(c[key], b[key], err_msg=f"{algo} {key}")
+            head = 3000
+            ref = _oracle.search(q, res[:off[head]], off[:head + 1], B62, 3, 1, "full", algo)
+            part = {k: (v[:head] if k != "aln" else v[:head]) for k, v in c.items() if k in ("score", "end_q", "end_t", "start_q", "start_t", "aln")}
+            compare(part, ref, "full", f"batches {algo}")
+    finally:
+        db.close()
+
+
 @pytest.mark.parametrize("qlen", [1, 7, 8, 9, 53, 63, 64, 65, 100, 128, 129, 200, 333])
 def test_query_lengths_sw_score(capi, qlen):
     # strip boundaries of the inter-sequence kernel (8-row blocks, 64-row strips)
