@@ -58,6 +58,20 @@ if os.environ.get("PHASES"):   # (the library's phase timers of three calls, not
             r = db.search(q, m, 3, 1, "full", "sw", reuse=r)
     db.close()
     sys.exit(0)
+if os.environ.get("AB_SWITCH"):   # (a tuning switch on and off by turns, same process: medians of 8 calls each)
+    name = os.environ["AB_SWITCH"]
+    r = db.search(q, m, 3, 1, "full", "sw")
+    for turn in range(6):
+        on = turn % 2 == 1
+        _capi.set_tuning(name, "1" if on else None)
+        r = db.search(q, m, 3, 1, "full", "sw", reuse=r)
+        ts = []
+        for _ in range(8):
+            t0 = time.perf_counter(); r = db.search(q, m, 3, 1, "full", "sw", reuse=r); ts.append(time.perf_counter() - t0)
+        print(f"{name} {'set  ' if on else 'unset'}: median {np.median(ts)*1e3:.2f} ms  min {min(ts)*1e3:.2f}", flush=True)
+    _capi.set_tuning(name, None)
+    db.close()
+    sys.exit(0)
 for label, hold, reuse in (("held, reuse", True, True), ("released between calls, reuse", False, True), ("released between calls, fresh arrays", False, False),
                            ("held, reuse", True, True)):
     r = db.search(q, m, 3, 1, "full", "sw")
