@@ -10,6 +10,9 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -460,6 +463,44 @@ void miopalTestInjectFault(int kind, int unit, int spinCap) {
 
 int miopalSelfTest(int which) {
     return guarded([&]() -> int {
+        if (which == 2) {
+            // the operations' way back from two bits each (unpack::, host_workspace.inc): every code path of this CPU -
+            // bit by bit, the table, pdep, AVX-512 VBMI, several threads, the crew started beforehand - against the
+            // definition, on ranges that start and end anywhere
+            const int64_t n = (9 << 20) + 37;
+            std::vector<uint8_t> ops((size_t)n), packed((size_t)(n + 3) / 4 + 64, 0), out((size_t)n + 64);
+            uint32_t x = 12345;
+            for (int64_t p = 0; p < n; ++p) {
+                x = x * 1664525u + 1013904223u;
+                ops[(size_t)p] = (uint8_t)(x >> 30);
+                packed[(size_t)(p >> 2)] |= (uint8_t)(ops[(size_t)p] << (2 * (p & 3)));
+            }
+            auto same = [&](int64_t from, int64_t to) {
+                for (int64_t p = from; p < to; ++p)
+                    if (out[(size_t)p] != ops[(size_t)p]) return false;
+                return true;
+            };
+            const int64_t cuts[][2] = {{0, n}, {1, n - 1}, {5, 77}, {63, 64}, {64, 64}, {7, 8 << 20}, {4097, n}, {n - 3, n}};
+            for (const auto& c : cuts) {
+                std::fill(out.begin(), out.end(), 9);
+                unpack::ops(out.data(), packed.data(), c[0], c[1], 8);
+                if (!same(c[0], c[1])) return 21;
+                if (c[0] > 0 && out[(size_t)c[0] - 1] != 9) return 22;   // (nothing written outside the range)
+                if (out[(size_t)c[1]] != 9) return 23;
+                std::fill(out.begin(), out.end(), 9);
+                unpack::rangePlain(out.data(), packed.data(), c[0], c[1]);
+                if (!same(c[0], c[1]) || out[(size_t)c[1]] != 9) return 24;
+                std::fill(out.begin(), out.end(), 9);
+                {
+                    unpack::Crew crew(7);
+                    crew.run(out.data(), packed.data(), c[0], c[1]);
+                }
+                if (!same(c[0], c[1])) return 100 + (int)(&c - &cuts[0]);   // (100 + the range's number: the crew left operations out)
+                if (out[(size_t)c[1]] != 9 || (c[0] > 0 && out[(size_t)c[0] - 1] != 9)) return 200 + (int)(&c - &cuts[0]);
+            }
+            { unpack::Crew unused(3); }   // (a crew that is never run goes away quietly)
+            return 0;
+        }
         if (which != 1) return -1;
         // (no device call on the way: the handle is never filled, the builders are injected)
         std::unique_ptr<MiopalDb> db(new MiopalDb());

@@ -99,6 +99,12 @@ def test_view_cache_survives_a_throwing_builder(capi):
     assert capi.lib().miopalSelfTest(99) != 0    # unknown test number
 
 
+def test_operations_unpacked_from_two_bits_each(capi):
+    # the host half of copy_out_packed_kernel (host_workspace.inc, unpack::): table / pdep / AVX-512 VBMI, whichever this
+    # CPU has, threaded and with the crew started beforehand, on ranges that start and end anywhere. Needs no device.
+    assert capi.lib().miopalSelfTest(2) == 0
+
+
 def test_tuning_switches_are_arguments_not_environment(capi, monkeypatch):
     """include/miopal.h, miopalSetTuning: the library reads MIOPAL_* from the environment once (tests/conftest.py
     sets MIOPAL_NO_SMALL_SEARCH before the first use); afterwards the environment is not looked at again - a
