@@ -48,6 +48,14 @@ if "q" in SUSTAIN:
     for mode in ("score", "end"):
         for _ in range(3):
             db.search(qq, m, 3, 1, mode, "sw")
+if "F" in SUSTAIN:   # (bench.py's Q = 300 `full` leg)
+    qq = _data.random_protein(np.random.default_rng(4), 300)
+    rr = None
+    for _ in range(6):
+        rr = db.search(qq, m, 3, 1, "full", "sw", reuse=rr)
+    del rr
+    for _ in range(7):
+        db.search(q, m, 3, 1, "end", "sw")
 print(f"before the full searches: {where()}, affinity {len(os.sched_getaffinity(0))} cpus", flush=True)
 for _ in range(2):
     db.search(q, m, 3, 1, "full", "sw")
