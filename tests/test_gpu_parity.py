@@ -239,6 +239,14 @@ def test_full_in_batches_with_and_without_the_side_stream_copies(capi, tuning):
             tuning.setenv("MIOPAL_NO_SIDE_COPIES", "1")
             b = db.search(q, B62, 3, 1, "full", algo)
             tuning.delenv("MIOPAL_NO_SIDE_COPIES")
+            # (the host's share of a batch behind the next batch's gather, the last share without the crew: round 4's first form)
+            tuning.setenv("MIOPAL_NO_EARLY_HOST_SHARE", "1")
+            tuning.setenv("MIOPAL_NO_UNPACK_CREW", "1")
+            d = db.search(q, B62, 3, 1, "full", algo)
+            tuning.delenv("MIOPAL_NO_EARLY_HOST_SHARE")
+            tuning.delenv("MIOPAL_NO_UNPACK_CREW")
+            for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
+                np.testing.assert_array_equal(d[key], b[key], err_msg=f"{algo} {key} (late host share)")
             c = db.search(q, B62, 3, 1, "full", algo, reuse=a)   # (and into the arrays and the operations buffer of `a`)
             for key in ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat"):
                 np.testing.assert_array_equal(c[key], b[key], err_msg=f"{algo} {key}")
