@@ -68,6 +68,20 @@ if os.environ.get("PHASES"):   # (the library's phase timers of three calls, not
     sys.exit(0)
 if os.environ.get("AB_SWITCH"):   # (a tuning switch on and off by turns, same process: medians of 8 calls each)
     name = os.environ["AB_SWITCH"]
+    ab_mode = os.environ.get("AB_MODE", "full")
+    if ab_mode != "full":   # (score / end searches into re-used, pageable arrays)
+        out = np.empty(len(off) - 1, dtype=np.int32)
+        for turn in range(6):
+            on = turn % 2 == 1
+            _capi.set_tuning(name, "1" if on else None)
+            r = db.search(q, m, 3, 1, ab_mode, "sw", score_out=out)
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter(); r = db.search(q, m, 3, 1, ab_mode, "sw", score_out=out, reuse=r); ts.append(time.perf_counter() - t0)
+            print(f"{ab_mode}: {name} {'set  ' if on else 'unset'}: median {np.median(ts)*1e3:.3f} ms  min {min(ts)*1e3:.3f}", flush=True)
+        _capi.set_tuning(name, None)
+        db.close()
+        sys.exit(0)
     r = db.search(q, m, 3, 1, "full", "sw")
     for turn in range(6):
         on = turn % 2 == 1
