@@ -186,6 +186,8 @@ void miopalLastRouting(int64_t counts[4]);
  *  16  operations copied to the host batch by batch beside the next batch
  *  32  start cells by persistent wavefronts whose lanes take the next pair when they are done
  *      (perpair_scan_refill_kernel: queries of one 64-row strip)
+ *  64  directions: two pairs per lane on 16-bit halves (perpair_packed.hip)
+ * 128  start cells: two pairs per lane on 16-bit halves
  * 0: no such search yet, or one whose traceback batches were built on the host.
  */
 int miopalLastFullRouting(void);

@@ -142,6 +142,7 @@ struct WalkArgs {
     int slotByOut;            // ops slot / opsLen entry = job.out instead of the job's position
     int queryLength;          // whole query (staged in LDS when it fits)
     int dirPlanes;            // lane-major directions are perpair_profile_kernel's bit planes
+    int dirColumnMajor;       // ... in lines of [column % 4][plane] dwords (perpair_packed.hip) instead of [plane][column % 4]
 };
 
 // perpair_kernel: one lane per (query window, target window) pair of a one-strip query
@@ -176,8 +177,26 @@ struct PerPairArgs {
     int* jobCounter;
     int computeUnits;
     int refillLanes;          // idle lanes of a wavefront that trigger a refill (set by launchPerPair)
+    // perpair_packed.hip (two pairs per lane on 16-bit halves): added to every profile entry so that it is an unsigned byte
+    int packedBias;
+    // perpair_packed.hip, one launch over the sorted lists of several batches (host_full.inc): jobs per batch (a multiple
+    // of 64; 0: the list is one batch). job.out is relative to its batch, and skipWaves holds one count per batch.
+    int outBatch;
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
+// perpair_packed.hip: the direction pass with two pairs per lane. packedTraceFits says whether it applies (rows /
+// columns: the tallest / longest window of the batch, strips and blocks of four rounded up; best: an upper bound of
+// any cell) and returns the bias, the profile stride and the LDS bytes to launch with. The planes leave in lines of
+// [column % 4][plane] dwords (WalkArgs::dirColumnMajor).
+constexpr int kPackedZero = 0x0800;
+bool packedTraceFits(int queryLength, int alphabet, int open, int ext, int maxScore, int minScore, int64_t rows,
+                     int64_t columns, int64_t best, int* bias, int* stride, size_t* ldsBytes);
+hipError_t launchPerPairPackedTrace(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream);
+// bytes per residue row of the lane-per-pair kernels' query profile: >= queryLength + 64 + 8, an odd number of dwords
+inline int perPairProfileStride(int queryLength) {
+    const int dwords = (queryLength + kLanes + 8 + 3) / 4;
+    return (dwords | 1) * 4;
+}
 // LDS bytes of the profile kernel for this query (0: too long for it), and the stride to pass
 size_t perPairProfileBytes(int queryLength, int alphabet, int* stride);
 

@@ -170,6 +170,7 @@ inline hipError_t createUploadStream(hipStream_t* s) {
 }
 
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
+constexpr int64_t kDirBudgetOneLaunch = 32ll << 30;   // directions of every batch of a `full` search at once (host_full.inc)
 constexpr int64_t kDirBudget = 2ll << 30;  // direction workspace: 2 x this per device-resident traceback batch, 1 x per host-built batch
 constexpr int64_t kInt32Safe = 1ll << 29;
 constexpr int kMaxDirectRecompute = 2048;  // lanes that left their range and are sent straight to int32: at least this many (see directLimit)

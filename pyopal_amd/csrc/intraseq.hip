@@ -760,7 +760,8 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                 --i;
             } else if (can) {
                 const int plane = state == 0 ? (probe ? 1 : 0) : state + 1;
-                const uint32_t bit = (lineLds[(plane * 4 + (j & 3)) * 64 + lane] >> (31 - (i & 31))) & 1u;
+                const int dword = a.dirColumnMajor ? (j & 3) * 4 + plane : plane * 4 + (j & 3);
+                const uint32_t bit = (lineLds[dword * 64 + lane] >> (31 - (i & 31))) & 1u;
                 if (state == 0) {
                     if (probe) {
                         state = bit ? 1 : 2;

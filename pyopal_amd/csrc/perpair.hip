@@ -789,7 +789,10 @@ __global__ __launch_bounds__(kBlock) void perpair_scan_refill_kernel(PerPairArgs
 
 // LDS of the profile kernel for a query of `queryLength` residues (0: the profile does not apply)
 size_t perPairProfileBytes(int queryLength, int alphabet, int* stride) {
-    const int pstride = (queryLength + kLanes + 8 + 3) & ~3;
+    // (an odd number of dwords: with a multiple of 128 bytes - a 53-residue query's 128 - every residue's row starts
+    // in the same LDS bank and the lanes of a read, which hold different residues at the same row, queue up behind one
+    // another: SQ_LDS_BANK_CONFLICT 88 % of the LDS cycles, the LDS busy half the kernel's time)
+    const int pstride = perPairProfileStride(queryLength);
     *stride = pstride;
     const size_t bytes = (size_t)(alphabet + 1) * pstride + 16;
     return bytes <= 64 * 1024 ? bytes : 0;

@@ -1,0 +1,479 @@
+// Two pairs per lane: the later passes of a `full` search on packed 16-bit halves (round 5).
+// src/pyopal/opal.pxd:17-19 (OPAL_SEARCH_ALIGNMENT); what the reference does with the result:
+// src/pyopal/platform/pyx.in:95-99, src/pyopal/lib.pyx:999-1037.
+//
+// perpair.hip gives every (query window, target window) problem of the traceback a lane of its own and
+// computes it at 32 bit: 15 VALU instructions per cell for the direction pass, 8 for the start-cell scan,
+// against 3.5 in the search kernels. Here a lane carries TWO unrelated pairs, one in each 16-bit half of its
+// registers - neither a shared query window nor a shared length is needed: each half reads its own residues
+// from the linear database and its own bytes of the query profile in LDS (one v_perm_b32 per row puts the two
+// scores side by side).
+//
+//   perpair_packed_trace_kernel   directions of the [start..end] rectangles as bit planes
+//
+// Values are unsigned patterns compared as half floats (interseq_impl.h, "biased integer halves"): between
+// 0x0400 and 0x7BFF the order of the bit patterns is the order of the numbers, so v_pk_maximum3_f16 folds two
+// max per cell while additions are plain 32-bit adds over both halves. Cells sit on the anti-diagonal scale
+// X'' = X + (i + j) ext (ArithU16Diag): both gap kinds extend for free and open with the same h - (open - ext),
+// and the stored H is that very number:
+//     d = HS(diag) + s''        s'' = S + open + ext (+ bias), an unsigned byte of the profile
+//     h = max3(d, E, F)
+//     hmo = h - c               c = open - ext; the next column's / row's stored H and the opener of both gaps
+//     E = max(E, hmo)   F = max(F, hmo)
+// With open >= ext every border value is the constant Z - 2 open on this scale.
+//
+// Direction flags without a packed compare. The four flags of a cell (came from the diagonal / from E / E was
+// opened / F was opened; same comparisons and tie-breaks as perpair_kernel) are all of the form "x - y == 0" or
+// "x - y >= c" for 0 <= x - y < 256 (bounded by the scoring scheme, see packedTraceFits). For t = 0x8000 - (x - y)
+// per half, bit 15 says "equal" and bits 8..14 all say "different": ONE 32-bit add per flag and cell pair (on
+// 0x8000 - h, shared by the four) and ONE v_bfi_b32 that drops the bit of row r into bit 15 - (r mod 8) of an
+// accumulator of eight rows - 10 full-rate adds + 4 v_bfi per cell PAIR where the 32-bit kernel needs
+// 4 x (v_sub + v_alignbit) per cell. Four accumulators are folded into the dword of 32 rows the walk reads by
+// three v_perm_b32.
+//
+// Model and tie-breaks: oracle/opal_oracle.c (rules 5-7).
+#include "common.h"
+#include "tuning.h"
+
+#include <type_traits>
+
+namespace miopal {
+
+namespace {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t pkMax3(uint32_t a, uint32_t b, uint32_t c) {
+    f16x2 r = __builtin_elementwise_maximum(
+        __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b)),
+        __builtin_bit_cast(f16x2, c));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t pkMax(uint32_t a, uint32_t b) {
+    f16x2 r = __builtin_elementwise_maximum(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+static __device__ __forceinline__ uint32_t both(int v) { return (uint32_t)v * 0x00010001u; }
+// (mask & a) | (~mask & b): one v_bfi_b32 (left to itself hipcc makes v_and + a share of a v_or3 of it)
+static __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {
+#ifndef MIOPAL_PACKED_NO_BFI
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "s"(mask), "v"(a), "v"(b));
+    return r;
+#else
+    return (a & mask) | (b & ~mask);
+#endif
+}
+
+// Workgroups of four wavefronts, two per CU (two wavefronts per SIMD), when their LDS fits twice - a workgroup's
+// slot is free again when its LAST wavefront is done, and eight sorted wavefronts differ by more than four - else
+// of eight.
+constexpr int kPkMaxWaves = 8;
+constexpr int kPkStageBytes = 16 * 1024;      // per wavefront: four columns x four lines x 64 lanes x 16 bytes
+constexpr int kPkZero = kPackedZero;          // pattern of the value 0
+constexpr uint32_t kPkC = 0x80008000u;
+
+// the lane's residues, four columns per load (perpair_profile_kernel): unconditional loads at addresses
+// clamped into the database, put in place when they are used
+struct ResidueStream {
+    const uint8_t* tptr;
+    const uint8_t* dbLo;
+    const uint8_t* dbHi;
+    uint32_t padWord;
+    int L;
+    __device__ __forceinline__ uint32_t fetchRaw(int j0) const {
+        const uint8_t* at = tptr + j0;
+        at = at < dbLo ? dbLo : at;
+        at = at > dbHi ? dbHi : at;
+        uint32_t w;
+        __builtin_memcpy(&w, at, 4);
+        return w;
+    }
+    __device__ __forceinline__ uint32_t inPlace(uint32_t raw, int j0) const {
+        const uint8_t* at = tptr + j0;
+        const int64_t below = dbLo - at, above = at - dbHi;   // > 0: the clamp moved the load by this many bytes
+        uint32_t w = raw;
+        if (below > 0) w = below >= 4 ? 0u : raw << (8 * (int)below);
+        if (above > 0) w = above >= 4 ? 0u : raw >> (8 * (int)above);
+        const int valid = L - j0;   // columns of the four that exist
+        const uint32_t keep = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : (1u << (8 * valid)) - 1u;
+        return (w & keep) | (padWord & ~keep);
+    }
+};
+
+// four accumulators of eight rows each (bits 15..8 = pair A's rows, 31..24 = pair B's) -> the dwords of 32 rows
+// of either pair, row 0 in bit 31
+static __device__ __forceinline__ void foldPlanes(const uint32_t acc[4], uint32_t& outA, uint32_t& outB) {
+    const uint32_t t01 = __builtin_amdgcn_perm(acc[0], acc[1], 0x07030501u);
+    const uint32_t t23 = __builtin_amdgcn_perm(acc[2], acc[3], 0x07030501u);
+    outA = __builtin_amdgcn_perm(t01, t23, 0x05040100u);
+    outB = __builtin_amdgcn_perm(t01, t23, 0x07060302u);
+}
+
+template <bool BIASED, int kPkWaves>
+__global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_kernel(PerPairArgs a) {
+    constexpr int kPkBlock = kPkWaves * kLanes;
+    extern __shared__ __attribute__((aligned(16))) uint8_t pkLds[];
+    uint4* const stageAll = reinterpret_cast<uint4*>(pkLds);
+    uint8_t* const prof = pkLds + kPkWaves * kPkStageBytes;
+    const int A = a.alphabet;
+    const int Qtot = a.queryLength;
+    const int pstride = a.profileStride;   // bytes per residue row, a multiple of 4, >= Qtot + 64 + 8
+    const int open = a.gapOpen, ext = a.gapExt, c = open - ext;
+    for (int idx = threadIdx.x; idx < (A + 1) * pstride; idx += kPkBlock) {
+        const int t = idx / pstride, y = idx - t * pstride;
+        int v = 0;   // padding symbol and rows: the lowest score
+        if (t < A && y < Qtot) v = a.matrix[(int)a.query[y] * A + t] + open + ext + a.packedBias;
+        prof[idx] = (uint8_t)v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = blockIdx.x * kPkWaves + wave;
+    const int idxA = W * 128 + lane, idxB = idxA + kLanes;
+    // (hybrid direction pass: the leading wavefronts' jobs - of 64 - are outliers done by intraseq_kernel)
+    // (one launch over several batches' lists: a count of leading wavefronts per batch, results relative to the batch)
+    int outBaseA = 0, outBaseB = 0;
+    bool activeA = idxA < a.nJobs, activeB = idxB < a.nJobs;
+    {
+        int batchA = 0, batchB = 0, inA = idxA >> 6, inB = idxB >> 6;   // wave-uniform all of them
+        if (a.outBatch > 0) {
+            batchA = idxA / a.outBatch;
+            batchB = idxB / a.outBatch;
+            outBaseA = batchA * a.outBatch;
+            outBaseB = batchB * a.outBatch;
+            inA -= outBaseA >> 6;
+            inB -= outBaseB >> 6;
+        }
+        if (a.skipWaves != nullptr) {
+            if (activeA && inA < a.skipWaves[batchA]) activeA = false;
+            if (activeB && inB < a.skipWaves[batchB]) activeB = false;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(activeA || activeB) == 0) return;
+    PairJob jobA{}, jobB{};
+    if (activeA) jobA = a.jobs[idxA];
+    if (activeB) jobB = a.jobs[idxB];
+    const int QA = jobA.qLen, LA = jobA.tLen, QB = jobB.qLen, LB = jobB.tLen;
+
+    int maxQ = max(QA, QB), maxL = max(LA, LB);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        maxQ = max(maxQ, __shfl_xor(maxQ, off));
+        maxL = max(maxL, __shfl_xor(maxL, off));
+    }
+    maxQ = __builtin_amdgcn_readfirstlane(maxQ);
+    maxL = __builtin_amdgcn_readfirstlane(maxL);
+    const int nStrips = (maxQ + kLanes - 1) / kLanes;
+
+    const uint32_t c2 = both(c), kc2 = kPkC + both(c - 1);
+    const uint32_t negBias2 = 0u - both(a.packedBias);
+    const uint32_t top2 = both(kPkZero - 2 * open);       // every border cell in stored form (open >= ext)
+    int bestA = INT32_MIN, bestB = INT32_MIN;
+
+    ResidueStream rsA{a.residues + jobA.tOff, a.residues, a.residues + a.residueCount - 4, (uint32_t)A * 0x01010101u, LA};
+    ResidueStream rsB{a.residues + jobB.tOff, a.residues, a.residues + a.residueCount - 4, (uint32_t)A * 0x01010101u, LB};
+    // strip boundaries of the wavefront: (stored H, F before it met that H) of the strip's last row, per column
+    uint2* bnd = a.boundary ? reinterpret_cast<uint2*>(a.boundary) + (int64_t)W * a.boundaryStride * kLanes + lane : nullptr;
+    // lines of the two pairs: [pair / 64][strip][column / 4][rows 0-31 | 32-63][pair % 64][column % 4][plane]
+    uint8_t* const dirsA = a.dirs + (int64_t)(idxA >> 6) * a.dirWaveStride + lane * 64;
+    uint8_t* const dirsB = a.dirs + (int64_t)(idxB >> 6) * a.dirWaveStride + lane * 64;
+    uint4* const stage = stageAll + wave * (kPkStageBytes / 16) + lane;   // [column % 4][line][lane]
+
+    // deposit masks: row r of a group of eight -> bit 15 - r of either half
+    // (wave-uniform constants: the compiler keeps them in SGPRs, one per v_bfi)
+    auto K = [](int r) -> uint32_t { return (0x8000u >> (r & 7)) * 0x00010001u; };
+
+    for (int s = 0; s < nStrips; ++s) {
+        const int row0 = s * kLanes;
+        const int rowsHere = min(maxQ - row0, kLanes);  // wave-uniform
+        // One strip of GROUPS x 8 rows. GROUPS is a compile-time constant (the switch below): with a run-time
+        // row count the unrolled rows need a way out every eight rows, and what is live where the ways out meet
+        // cost the kernel a hundred spilled registers.
+        auto sweepStrip = [&](auto groupsTag) {
+            constexpr int GROUPS = decltype(groupsTag)::value, ROWS = GROUPS * 8;
+            const bool toNext = s + 1 < nStrips;
+            // the halves' first rows along the profile; rows beyond the query read the pad bytes behind it
+            const int ysA = min(jobA.qOff + row0, Qtot), ysB = min(jobB.qOff + row0, Qtot);
+            const uint32_t shiftA = (uint32_t)ysA & 3u, shiftB = (uint32_t)ysB & 3u;
+            const int yAlA = ysA & ~3, yAlB = ysB & ~3;
+            uint32_t HS[ROWS], E[ROWS];
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) HS[i] = E[i] = top2;   // column -1
+            uint8_t* const stripA = dirsA + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
+            uint8_t* const stripB = dirsB + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
+            // the cell above-left of the strip's first cell: the origin (value 0 two steps up the scale) or a border cell
+            uint32_t aboveHsPrev = s == 0 ? both(kPkZero - 2 * ext - c) : top2;
+            const int lastLocalA = QA - 1 - row0, lastLocalB = QB - 1 - row0;
+
+            // the halves' residues, four columns per load; the column's own pair is picked a column ahead so that
+            // the first profile dwords of column j + 1 can be fetched while column j is computed
+            uint32_t wcurA = rsA.inPlace(rsA.fetchRaw(0), 0), rawNextA = rsA.fetchRaw(4);
+            uint32_t wcurB = rsB.inPlace(rsB.fetchRaw(0), 0), rawNextB = rsB.fetchRaw(4);
+            uint2 aboveNext = make_uint2(top2, top2);
+            if (s > 0) aboveNext = bnd[0];
+            const int sweep = (maxL + 3) & ~3;
+            // "E was opened" of column j is known when column j - 1 is done: the planes of the column before wait
+            // here (column 0 opens from the border)
+            uint32_t prevO[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};   // [A rows 0-31, A 32-63, B 0-31, B 32-63]
+            auto rowOf = [&](uint32_t t, int yAl) { return reinterpret_cast<const uint32_t*>(prof + t * pstride + yAl); };
+            const uint32_t* prowA = rowOf(wcurA & 0xffu, yAlA);
+            const uint32_t* prowB = rowOf(wcurB & 0xffu, yAlB);
+            // An LDS read queues behind the other wavefronts' reads: the dwords of a column are fetched three blocks of
+            // four rows ahead of their use, the first three while the column before is still being computed
+            // (with a read per block, used at once: SQ_WAIT_ANY 39 % of the wavefronts' cycles)
+            uint32_t pA0 = prowA[0], pA1 = prowA[1], pA2 = prowA[2];
+            uint32_t pB0 = prowB[0], pB1 = prowB[1], pB2 = prowB[2];
+            for (int j = 0; j < sweep; ++j) {
+                // the residues of the next column
+                uint32_t tnA, tnB;
+                if ((j & 3) == 3) {
+                    wcurA = rsA.inPlace(rawNextA, j + 1);
+                    rawNextA = rsA.fetchRaw(j + 5);
+                    wcurB = rsB.inPlace(rawNextB, j + 1);
+                    rawNextB = rsB.fetchRaw(j + 5);
+                    tnA = wcurA & 0xffu;
+                    tnB = wcurB & 0xffu;
+                } else {
+                    tnA = (wcurA >> (8 * ((j & 3) + 1))) & 0xffu;
+                    tnB = (wcurB >> (8 * ((j & 3) + 1))) & 0xffu;
+                }
+                const uint32_t* const prowNextA = rowOf(tnA, yAlA);
+                const uint32_t* const prowNextB = rowOf(tnB, yAlB);
+                uint32_t hsUp = top2, fOldUp = top2;
+                if (s > 0) {
+                    const uint2 above = aboveNext;
+                    aboveNext = bnd[(int64_t)min(j + 1, maxL - 1) * kLanes];   // (unconditional: no copy behind the load)
+                    hsUp = above.x;
+                    fOldUp = above.y;
+                }
+                uint32_t hsDiag = aboveHsPrev;
+                aboveHsPrev = hsUp;
+                // F of the first row, and whether it was opened: not opened <=> fOld > hsUp <=> bit 15 of fOld + 0x7fff - hsUp
+                uint32_t F = pkMax(fOldUp, hsUp);
+                uint32_t fOldLast = fOldUp;
+                uint32_t accD[4], accE[4], accO[4], accF[5];   // of the half strip at hand
+                accF[0] = (fOldUp + (kPkC - 0x00010001u) - hsUp) & K(0);
+                uint32_t wloA = pA0, wloB = pB0, n1A = pA1, n1B = pB1, n2A = pA2, n2B = pB2, fourA = 0, fourB = 0;
+                constexpr int kLastDword = ROWS / 4;                       // dwords 0 .. ROWS / 4 of the rows are read
+                constexpr int kNextAt = ROWS >= 12 ? ROWS / 4 - 3 : 0;     // block at which the next column's are
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i) {
+                    if ((i & 3) == 0) {
+                        const int blk = i >> 2;
+                        const uint32_t whiA = n1A, whiB = n1B;
+                        fourA = __builtin_amdgcn_alignbyte(whiA, wloA, shiftA);
+                        fourB = __builtin_amdgcn_alignbyte(whiB, wloB, shiftB);
+                        wloA = whiA;
+                        wloB = whiB;
+                        n1A = n2A;
+                        n1B = n2B;
+                        if (blk + 3 <= kLastDword) {
+                            n2A = prowA[blk + 3];
+                            n2B = prowB[blk + 3];
+                        }
+                        if (blk == kNextAt) {
+                            pA0 = prowNextA[0]; pA1 = prowNextA[1]; pA2 = prowNextA[2];
+                            pB0 = prowNextB[0]; pB1 = prowNextB[1]; pB2 = prowNextB[2];
+                        }
+                    }
+                    // {0, B's byte, 0, A's byte}
+                    const uint32_t ub2 = __builtin_amdgcn_perm(fourB, fourA, 0x0c040c00u + (uint32_t)(i & 3) * 0x00010001u);
+                    uint32_t d = hsDiag + ub2;
+                    if (BIASED) d += negBias2;
+                    const uint32_t eOld = E[i];
+                    const uint32_t h = pkMax3(d, eOld, F);
+                    const uint32_t hC = kPkC - h;           // 0x8000 - h per half
+                    const uint32_t hC2 = kc2 - h;           // 0x8000 + c - 1 - h
+                    const int g = (i >> 3) & 3;             // group of eight rows inside the half strip
+                    if ((i & 7) == 0) {
+                        accD[g] = (d + hC) & K(i);
+                        accE[g] = (eOld + hC) & K(i);
+                        accO[g] = (eOld + hC2) & K(i);
+                    } else {
+                        accD[g] = bfi(K(i), d + hC, accD[g]);
+                        accE[g] = bfi(K(i), eOld + hC, accE[g]);
+                        accO[g] = bfi(K(i), eOld + hC2, accO[g]);
+                    }
+                    // "F was opened" belongs to the row below
+                    if ((i & 7) == 7) accF[g + 1] = (F + hC2) & K(i + 1);
+                    else accF[g] = bfi(K(i + 1), F + hC2, accF[g]);
+                    const uint32_t hmo = h - c2;
+                    E[i] = pkMax(eOld, hmo);
+                    fOldLast = F;
+                    F = pkMax(F, hmo);
+                    hsDiag = HS[i];
+                    HS[i] = hmo;
+                    // pins the schedule: hipcc would otherwise hoist every ds_read of the column to its top
+                    if ((i & 3) == 3) asm volatile("" : "+v"(F), "+v"(hsDiag)::"memory");
+                    if ((i & 31) == 31 || i == ROWS - 1) {
+                        // A half strip is complete: fold its planes and put the column's 16 bytes of either pair into
+                        // the wavefront's staging lines (bits of rows the half strip does not hold are never read).
+                        // Polarity: "equal" planes are true in bit 15 of their group and inverted below it, "opened"
+                        // planes the other way round.
+                        const int hs = i >> 5, held = ((i & 31) >> 3) + 1;
+                        uint32_t aD[4], aE[4], aO[4], aF[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            aD[x] = x < held ? accD[x] : 0u;
+                            aE[x] = x < held ? accE[x] : 0u;
+                            aO[x] = x < held ? accO[x] : 0u;
+                            aF[x] = x < held ? accF[x] : 0u;
+                        }
+                        uint32_t dA, dB, eA, eB, oA, oB, fA, fB;
+                        foldPlanes(aD, dA, dB);
+                        foldPlanes(aE, eA, eB);
+                        foldPlanes(aO, oA, oB);
+                        foldPlanes(aF, fA, fB);
+                        stage[((j & 3) * 4 + hs) * kLanes] = make_uint4(dA ^ 0x7f7f7f7fu, eA ^ 0x7f7f7f7fu, prevO[hs], fA ^ 0x80808080u);
+                        stage[((j & 3) * 4 + 2 + hs) * kLanes] = make_uint4(dB ^ 0x7f7f7f7fu, eB ^ 0x7f7f7f7fu, prevO[2 + hs], fB ^ 0x80808080u);
+                        prevO[hs] = oA ^ 0x80808080u;
+                        prevO[2 + hs] = oB ^ 0x80808080u;
+                        accF[0] = accF[4];   // (row 32's flag came with row 31)
+                    }
+                }
+                prowA = prowNextA;
+                prowB = prowNextB;
+                if (ROWS == kLanes && toNext && j < maxL) bnd[(int64_t)j * kLanes] = make_uint2(HS[ROWS - 1], fOldLast);
+                if ((j & 3) == 3) {
+                    // block of four columns: the lane's lines leave for HBM whole, 64 bytes each
+                    const int64_t blockOff = (int64_t)(j >> 2) * (2 * kLanes * 64);
+#pragma unroll
+                    for (int hs = 0; hs < (ROWS > 32 ? 2 : 1); ++hs) {
+                        uint4* const toA = reinterpret_cast<uint4*>(stripA + blockOff + hs * (kLanes * 64));
+                        uint4* const toB = reinterpret_cast<uint4*>(stripB + blockOff + hs * (kLanes * 64));
+                        // (one line at a time: sixteen reads in flight at once would take 64 registers)
+                        {
+                            const uint4 v0 = stage[(0 * 4 + hs) * kLanes], v1 = stage[(1 * 4 + hs) * kLanes],
+                                        v2 = stage[(2 * 4 + hs) * kLanes], v3 = stage[(3 * 4 + hs) * kLanes];
+                            if (activeA) {
+                                toA[0] = v0; toA[1] = v1; toA[2] = v2; toA[3] = v3;
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                        {
+                            const uint4 v0 = stage[(0 * 4 + 2 + hs) * kLanes], v1 = stage[(1 * 4 + 2 + hs) * kLanes],
+                                        v2 = stage[(2 * 4 + 2 + hs) * kLanes], v3 = stage[(3 * 4 + 2 + hs) * kLanes];
+                            if (activeB) {
+                                toB[0] = v0; toB[1] = v1; toB[2] = v2; toB[3] = v3;
+                            }
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                // score of a window = its last cell; lanes of a wavefront (sorted by length) finish in a handful of
+                // columns, so the row select runs rarely
+                const bool mineA = j == LA - 1 && lastLocalA >= 0 && lastLocalA < ROWS;
+                const bool mineB = j == LB - 1 && lastLocalB >= 0 && lastLocalB < ROWS;
+                if (__builtin_amdgcn_ballot_w64(mineA || mineB) != 0) {
+                    uint32_t vA = 0, vB = 0;
+                    // (opaque here: the comparisons would otherwise be hoisted out of the column loop as lane masks
+                    // kept - and spilled - across it)
+                    int llA = lastLocalA, llB = lastLocalB;
+                    asm volatile("" : "+v"(llA), "+v"(llB));
+#pragma unroll
+                    for (int i = 0; i < ROWS; ++i) {
+                        vA = (i == llA) ? HS[i] : vA;
+                        vB = (i == llB) ? HS[i] : vB;
+                    }
+                    if (mineA) bestA = (int)(vA & 0xffffu) - kPkZero + c - (QA - 1 + j) * ext;
+                    if (mineB) bestB = (int)(vB >> 16) - kPkZero + c - (QB - 1 + j) * ext;
+                }
+            }
+        };
+        using std::integral_constant;
+        switch ((rowsHere + 7) >> 3) {   // wave-uniform
+            case 1: sweepStrip(integral_constant<int, 1>{}); break;
+            case 2: sweepStrip(integral_constant<int, 2>{}); break;
+            case 3: sweepStrip(integral_constant<int, 3>{}); break;
+            case 4: sweepStrip(integral_constant<int, 4>{}); break;
+            case 5: sweepStrip(integral_constant<int, 5>{}); break;
+            case 6: sweepStrip(integral_constant<int, 6>{}); break;
+            case 7: sweepStrip(integral_constant<int, 7>{}); break;
+            default: sweepStrip(integral_constant<int, 8>{}); break;
+        }
+    }
+
+    auto finish = [&](bool active, const PairJob& job, int best, int outBase) {
+        if (!active) return;
+        if (!(job.qLen > 0 && job.tLen > 0)) {
+            // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+            best = 0;
+            if (job.qLen > 0) best = borderGap(job.qLen - 1, open, ext);
+            if (job.tLen > 0) best = borderGap(job.tLen - 1, open, ext);
+        }
+        a.score[outBase + job.out] = best;
+    };
+    finish(activeA, jobA, bestA, outBaseA);
+    finish(activeB, jobB, bestB, outBaseB);
+}
+
+}  // namespace
+
+// Does the packed direction pass apply? (host side: host_full.inc)
+//   open >= ext >= 0                                   borders are constants on the anti-diagonal scale
+//   S + open + ext + bias in [0, 255]                  the profile holds unsigned bytes
+//   maxS+ + open + max(open, -minS) <= 255             the flags' differences stay below 256 (see the proof in DESIGN.md)
+//   Z - 4 open - ext - bias >= 0x0400, Z + best + (rows + columns) ext + slack <= 0x7BFF   normal half floats
+// best: an upper bound of any cell of any window (min(rows, columns) x maxS+, or the query's own best).
+bool packedTraceFits(int queryLength, int alphabet, int open, int ext, int maxScore, int minScore, int64_t rows,
+                     int64_t columns, int64_t best, int* bias, int* stride, size_t* ldsBytes) {
+    if (!(open >= ext && ext >= 0)) return false;
+    const int b = std::max(0, -(minScore + open + ext));
+    const int maxPos = std::max(maxScore, 0);
+    if (maxScore + open + ext + b > 255) return false;
+    if (maxPos + open + std::max(open, -minScore) > 255) return false;
+    if (kPackedZero - 4 * (int64_t)open - ext - b < 0x0400) return false;
+    const int64_t slack = 2 * ((int64_t)maxPos + open + ext) + b;
+    if (kPackedZero + std::max<int64_t>(best, 0) + (rows + columns) * ext + slack > 0x7BFF) return false;
+    const int pstride = perPairProfileStride(queryLength);
+    const size_t profile = (size_t)(alphabet + 1) * pstride + 16;
+    // (two workgroups of four wavefronts per CU when they fit its 160 KB, one of eight otherwise)
+    size_t bytes = 4 * (size_t)kPkStageBytes + profile;
+    if (2 * bytes > 156 * 1024) bytes = (size_t)kPkMaxWaves * kPkStageBytes + profile;
+    if (bytes > 160 * 1024) return false;
+    *bias = b;
+    *stride = pstride;
+    *ldsBytes = bytes;
+    return true;
+}
+
+static inline bool firstUseHere(uint64_t* seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    const uint64_t bit = 1ull << dev;
+    const uint64_t old = __atomic_fetch_or(seen, bit, __ATOMIC_RELAXED);
+    return !(old & bit);
+}
+
+template <bool BIASED, int WAVES>
+static hipError_t launchPackedTraceAs(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream) {
+    static uint64_t configured = 0;   // one bit per device: the attribute belongs to the device
+    if (firstUseHere(&configured)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&perpair_packed_trace_kernel<BIASED, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            __atomic_fetch_and(&configured, ~(1ull << dev), __ATOMIC_RELAXED);
+            return e;
+        }
+    }
+    const int waves = (a.nJobs + 2 * kLanes - 1) / (2 * kLanes);
+    hipLaunchKernelGGL((perpair_packed_trace_kernel<BIASED, WAVES>), dim3((waves + WAVES - 1) / WAVES), dim3(WAVES * kLanes),
+                       ldsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchPerPairPackedTrace(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    if (a.profileStride <= 0 || a.dirs == nullptr || (a.dirStripColumns & 3)) return hipErrorInvalidValue;
+    const size_t profile = (size_t)(a.alphabet + 1) * a.profileStride + 16;
+    const bool four = ldsBytes == 4 * (size_t)kPkStageBytes + profile;
+    if (a.packedBias > 0) {
+        return four ? launchPackedTraceAs<true, 4>(a, ldsBytes, stream) : launchPackedTraceAs<true, kPkMaxWaves>(a, ldsBytes, stream);
+    }
+    return four ? launchPackedTraceAs<false, 4>(a, ldsBytes, stream) : launchPackedTraceAs<false, kPkMaxWaves>(a, ldsBytes, stream);
+}
+
+}  // namespace miopal
