@@ -182,6 +182,9 @@ struct PerPairArgs {
     // perpair_packed.hip, one launch over the sorted lists of several batches (host_full.inc): jobs per batch (a multiple
     // of 64; 0: the list is one batch). job.out is relative to its batch, and skipWaves holds one count per batch.
     int outBatch;
+    // perpair_packed_scan_kernel / perpair_packed_scan_strips_kernel (the latter's rows between strips: `boundary`,
+    // [job / 128][column][lane] x 8 bytes)
+    int packedZero;           // pattern of the value 0 (packedScanFits)
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 // perpair_packed.hip: the direction pass with two pairs per lane. packedTraceFits says whether it applies (rows /
@@ -192,6 +195,11 @@ constexpr int kPackedZero = 0x0800;
 bool packedTraceFits(int queryLength, int alphabet, int open, int ext, int maxScore, int minScore, int64_t rows,
                      int64_t columns, int64_t best, int* bias, int* stride, size_t* ldsBytes);
 hipError_t launchPerPairPackedTrace(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream);
+// the start-cell scan of Smith-Waterman searches with two pairs per lane (persistent wavefronts, a.jobCounter zeroed):
+// longest = the longest prefix, best = an upper bound of the optimum
+bool packedScanFits(int queryLength, int alphabet, int open, int ext, int maxScore, int minScore, int64_t longest,
+                    int64_t best, int* bias, int* zero, int* stride, size_t* ldsBytes);
+hipError_t launchPerPairPackedScan(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream);
 // bytes per residue row of the lane-per-pair kernels' query profile: >= queryLength + 64 + 8, an odd number of dwords
 inline int perPairProfileStride(int queryLength) {
     const int dwords = (queryLength + kLanes + 8 + 3) / 4;

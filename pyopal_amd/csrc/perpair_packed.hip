@@ -408,6 +408,292 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
     finish(activeB, jobB, bestB, outBaseB);
 }
 
+
+// ---- the start-cell scan with two pairs per lane -------------------------------------------------------
+// The reversed-prefix scans (perpair.hip: perpair_scan_refill_kernel, perpair_profile_kernel<kAllCells>) on the
+// same halves. Persistent wavefronts; every HALF of a lane runs its own schedule: its own pair, its own strip of
+// 64 query rows, its own column - a half that is done with a strip goes on to the pair's next strip, a half that
+// is done with its pair takes the next pair of the list (one atomic per wavefront and refill), at multiples of
+// four columns so that the four-residue loads stay in step. Between strips the last row travels through a
+// private line of HBM per half, 4 bytes per column, read back one column ahead; strip 0 "reads" a constant
+// line that holds the border.
+//
+// Cells on the column scale X' = X + j ext, everything times 8: the three low bits of a value are free and the
+// column's maximum is folded over KEYS, value + 7 - (group of eight rows), so that the maximum itself says which
+// group holds its first row - the known optimum of the forward pass is met once per pair and strip, but with 128
+// pairs per wavefront that is nearly every column, and finding the row by comparison cost a third of a column:
+//     d = HS(diag) + s'        s' = 8 (S + open + bias), an unsigned byte of the profile (S + open + bias <= 31)
+//     e = max(E, HS)           (extending is free on this scale)
+//     f = max(F, HS above) - 8 ext
+//     h = max3(d, e, f);  HS = h - 8 (open - ext)
+// No cell of an anchored scan exceeds the optimum, so "the column's maximum equals the optimum" is the hit, and the
+// first column-major cell that holds it is the start cell (oracle/opal_oracle.c, rule 6).
+constexpr int kScanBlock = 256;
+constexpr int kScanWaves = kScanBlock / kLanes;
+
+struct ScanHalf {
+    int Q, need, out, j, y0, strip, bcol, brow;
+    uint32_t wcur, rawNext;
+    const uint8_t* tptr;
+};
+
+template <int GROUPS, bool BIASED>
+__global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPairArgs a) {
+    constexpr int ROWS = GROUPS * 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t pkLds[];
+    uint8_t* const prof = pkLds;
+    const int A = a.alphabet;
+    const int Qtot = a.queryLength;
+    const int pstride = a.profileStride;
+    const int open = a.gapOpen, ext = a.gapExt;
+    const int Z = a.packedZero;   // pattern of the value 0 on column 0: a multiple of 8 that leaves room for the last row's border
+    for (int idx = threadIdx.x; idx < (A + 1) * pstride; idx += kScanBlock) {
+        const int t = idx / pstride, y = idx - t * pstride;
+        int v = 0;
+        if (t < A && y < Qtot) v = 8 * (a.matrix[(int)a.query[Qtot - 1 - y] * A + t] + open + a.packedBias);
+        prof[idx] = (uint8_t)v;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t ext2 = both(8 * ext), c2 = both(8 * (open - ext));
+    const uint32_t negBias2 = 0u - both(8 * a.packedBias);
+    const int topPat = Z - 8 * (2 * open - ext);       // row -1 in stored form, any column but -1
+    const uint32_t top2 = both(topPat);
+    const uint32_t padWord = (uint32_t)A * 0x01010101u;
+    const uint8_t* const dbLo = a.residues;
+    const uint8_t* const dbHi = a.residues + a.residueCount - 4;
+
+    ScanHalf hA{}, hB{};
+    bool busyA = false, busyB = false;
+    hA.tptr = hB.tptr = a.residues;
+    hA.wcur = hB.wcur = hA.rawNext = hB.rawNext = padWord;
+    hA.bcol = hB.bcol = hA.brow = hB.brow = -1;
+    uint32_t tgt2 = 0xffffffffu;      // pattern of the optimum on the halves' current columns (idle: never met)
+    uint32_t incr2 = 0;               // what a column adds to it (busy halves)
+    uint32_t aboveHsPrev = top2;
+    uint32_t yAl2 = 0, shiftA = 0, shiftB = 0;   // (yAl2: the halves' aligned profile offsets, 16 bits each)
+    uint32_t HS[ROWS], E[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) HS[i] = E[i] = top2;
+    bool exhausted = false;   // wave-uniform: no pair left to take
+
+    auto fetchRaw = [&](const ScanHalf& h, int j0) -> uint32_t {
+        const uint8_t* at = h.tptr - j0 - 3;
+        at = at < dbLo ? dbLo : at;
+        at = at > dbHi ? dbHi : at;
+        uint32_t w;
+        __builtin_memcpy(&w, at, 4);
+        return w;
+    };
+    auto inPlace = [&](const ScanHalf& h, int L, uint32_t raw, int j0) -> uint32_t {
+        const uint8_t* at = h.tptr - j0 - 3;
+        const int64_t below = dbLo - at, above = at - dbHi;
+        uint32_t w = raw;
+        if (below > 0) w = below >= 4 ? 0u : raw << (8 * (int)below);
+        if (above > 0) w = above >= 4 ? 0u : raw >> (8 * (int)above);
+        w = __builtin_bswap32(w);
+        const int valid = L - j0;
+        const uint32_t keep = valid >= 4 ? 0xffffffffu : valid <= 0 ? 0u : (1u << (8 * valid)) - 1u;
+        return (w & keep) | (padWord & ~keep);
+    };
+    // (the pair's target length: the prefix ends where the job says; `need` shrinks, the length does not)
+    int LA = 0, LB = 0;
+    int stopA = 0, stopB = 0;
+
+    for (int w = 0;; ++w) {
+        if ((w & 3) == 0) {
+            // ---- service: halves that go on to their pair's next strip, halves that take a new pair
+            const bool wantA = !busyA, wantB = !busyB;
+            const uint64_t maskA = __builtin_amdgcn_ballot_w64(wantA), maskB = __builtin_amdgcn_ballot_w64(wantB);
+            const int idle = __builtin_popcountll(maskA) + __builtin_popcountll(maskB);
+            if (exhausted && idle == 2 * kLanes) break;
+            const bool refill = !exhausted && idle > 0 && (idle >= a.refillLanes || w == 0);
+            if (refill) {
+                bool startA = false, startB = false;
+                {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(a.jobCounter, idle);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + idle >= a.nJobs) exhausted = true;
+                    const int rankA = __builtin_amdgcn_mbcnt_hi((uint32_t)(maskA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)maskA, 0));
+                    const int rankB = __builtin_popcountll(maskA) +
+                                      __builtin_amdgcn_mbcnt_hi((uint32_t)(maskB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)maskB, 0));
+                    auto take = [&](bool want, int k, ScanHalf& h, int& L, int& stop, bool& start) {
+                        if (!want || k >= a.nJobs) return;
+                        const PairJob job = a.jobs[k];
+                        h.Q = job.qLen;
+                        L = job.tLen;
+                        h.need = L;
+                        h.out = job.out;
+                        stop = job.stop;
+                        h.tptr = a.residues + job.tOff;
+                        h.y0 = Qtot - 1 - job.qOff;
+                        h.strip = -1;
+                        h.bcol = h.brow = -1;
+                        if (job.qLen > 0 && job.tLen > 0) {
+                            start = true;
+                        } else {
+                            // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
+                            int v = 0;
+                            if (job.qLen > 0) v = borderGap(job.qLen - 1, open, ext);
+                            if (job.tLen > 0) v = borderGap(job.tLen - 1, open, ext);
+                            a.score[job.out] = v;
+                            if (a.endI) a.endI[job.out] = -1;
+                            if (a.endJ) a.endJ[job.out] = -1;
+                        }
+                    };
+                    take(wantA, base + rankA, hA, LA, stopA, startA);
+                    take(wantB, base + rankB, hB, LB, stopB, startB);
+                }
+                if (__builtin_amdgcn_ballot_w64(startA || startB) != 0) {
+                    // a half starts a strip: column 0 of it, its rows on the border, its own optimum to meet
+                    auto begin = [&](bool start, ScanHalf& h) {
+                        if (!start) return;
+                        h.strip += 1;
+                        h.j = 0;
+                        h.rawNext = fetchRaw(h, 0);
+                    };
+                    begin(startA, hA);
+                    begin(startB, hB);
+                    const uint32_t m2 = (startA ? 0x0000ffffu : 0u) | (startB ? 0xffff0000u : 0u);
+                    const int rowA0 = hA.strip * kLanes, rowB0 = hB.strip * kLanes;
+                    // rows: H[i][-1] = -(open + i ext) one column to the left of column 0: stored form Z - 8 (2 open + i ext)
+                    const uint32_t baseRows = ((uint32_t)(Z - 8 * (2 * open + rowA0 * ext)) & 0xffffu) |
+                                              ((uint32_t)(Z - 8 * (2 * open + rowB0 * ext)) << 16);
+#pragma unroll
+                    for (int i = 0; i < ROWS; ++i) {
+                        const uint32_t v = baseRows - both(8 * i * ext);
+                        HS[i] = (v & m2) | (HS[i] & ~m2);
+                        E[i] = (v & m2) | (E[i] & ~m2);
+                    }
+                    // the cell above-left of the strip: the origin (0 on column -1's scale) or a border cell
+                    const int diagA = rowA0 == 0 ? Z - 8 * open : Z - 8 * (2 * open + (rowA0 - 1) * ext);
+                    const int diagB = rowB0 == 0 ? Z - 8 * open : Z - 8 * (2 * open + (rowB0 - 1) * ext);
+                    const uint32_t diag2 = ((uint32_t)diagA & 0xffffu) | ((uint32_t)diagB << 16);
+                    aboveHsPrev = (diag2 & m2) | (aboveHsPrev & ~m2);
+                    const uint32_t t2 = ((uint32_t)(Z + 8 * stopA) & 0xffffu) | ((uint32_t)(Z + 8 * stopB) << 16);
+                    tgt2 = (t2 & m2) | (tgt2 & ~m2);
+                    const int ysA = min(hA.y0 + rowA0, Qtot), ysB = min(hB.y0 + rowB0, Qtot);
+                    if (startA) {
+                        shiftA = (uint32_t)ysA & 3u;
+                        yAl2 = (yAl2 & 0xffff0000u) | (uint32_t)(ysA & ~3);
+                        busyA = true;
+                    }
+                    if (startB) {
+                        shiftB = (uint32_t)ysB & 3u;
+                        yAl2 = (yAl2 & 0x0000ffffu) | ((uint32_t)(ysB & ~3) << 16);
+                        busyB = true;
+                    }
+                    incr2 = (busyA ? (uint32_t)(8 * ext) : 0u) | (busyB ? (uint32_t)(8 * ext) << 16 : 0u);
+                }
+                if (exhausted && __builtin_amdgcn_ballot_w64(busyA || busyB) == 0) break;
+            }
+            hA.wcur = inPlace(hA, LA, hA.rawNext, hA.j);
+            hA.rawNext = fetchRaw(hA, hA.j + 4);
+            hB.wcur = inPlace(hB, LB, hB.rawNext, hB.j);
+            hB.rawNext = fetchRaw(hB, hB.j + 4);
+        }
+        const uint32_t tA = (hA.wcur >> (8 * (w & 3))) & 0xffu, tB = (hB.wcur >> (8 * (w & 3))) & 0xffu;
+        const uint32_t* prowA = reinterpret_cast<const uint32_t*>(prof + tA * pstride + (yAl2 & 0xffffu));
+        const uint32_t* prowB = reinterpret_cast<const uint32_t*>(prof + tB * pstride + (yAl2 >> 16));
+        uint32_t hsUp = top2, F = top2;
+        uint32_t hsDiag = aboveHsPrev;
+        aboveHsPrev = hsUp;
+        uint32_t gm[GROUPS];
+        uint32_t held = 0;
+        uint32_t wloA = prowA[0], wloB = prowB[0], n1A = prowA[1], n1B = prowB[1], fourA = 0, fourB = 0;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if ((i & 3) == 0) {
+                const int blk = i >> 2;
+                const uint32_t whiA = n1A, whiB = n1B;
+                fourA = __builtin_amdgcn_alignbyte(whiA, wloA, shiftA);
+                fourB = __builtin_amdgcn_alignbyte(whiB, wloB, shiftB);
+                wloA = whiA;
+                wloB = whiB;
+                if (blk + 2 <= ROWS / 4) {
+                    n1A = prowA[blk + 2];
+                    n1B = prowB[blk + 2];
+                }
+            }
+            const uint32_t ub2 = __builtin_amdgcn_perm(fourB, fourA, 0x0c040c00u + (uint32_t)(i & 3) * 0x00010001u);
+            uint32_t d = hsDiag + ub2;
+            if (BIASED) d += negBias2;
+            const uint32_t e = pkMax(E[i], HS[i]);
+            const uint32_t f = pkMax(F, hsUp) - ext2;
+            const uint32_t h = pkMax3(d, e, f);
+            // the group's maximum, two rows a step
+            const int r = i & 7, g = i >> 3;
+            if (r == 1) gm[g] = pkMax(held, h);
+            else if (r & 1) gm[g] = pkMax3(gm[g], held, h);
+            else held = h;
+            const uint32_t hs = h - c2;
+            hsDiag = HS[i];
+            HS[i] = hs;
+            E[i] = e;
+            F = f;
+            hsUp = hs;
+            if ((i & 3) == 3) asm volatile("" : "+v"(F), "+v"(hsDiag)::"memory");
+        }
+        // the column's maximum over keys: value + 7 - group, i.e. the first group that holds it
+        uint32_t cmk = gm[0] + both(7);
+#pragma unroll
+        for (int g = 1; g < GROUPS; g += 2) {
+            if (g + 1 < GROUPS) cmk = pkMax3(cmk, gm[g] + both(7 - g), gm[g + 1] + both(6 - g));
+            else cmk = pkMax(cmk, gm[g] + both(7 - g));
+        }
+        const uint32_t x = (cmk & 0xfff8fff8u) ^ tgt2;
+        const bool hitA = busyA && (x & 0xffffu) == 0, hitB = busyB && (x >> 16) == 0;
+        if (__builtin_amdgcn_ballot_w64(hitA || hitB) != 0) {
+            const int gstarA = 7 - (int)(cmk & 7u), gstarB = 7 - (int)((cmk >> 16) & 7u);
+            int rowA = 0, rowB = 0;
+#pragma unroll
+            for (int g = 0; g < GROUPS; ++g) {
+                const bool inA = hitA && gstarA == g, inB = hitB && gstarB == g;
+                if (__builtin_amdgcn_ballot_w64(inA || inB) == 0) continue;
+                // the first row of the group that holds the group's maximum: keys again, value + 7 - row
+                uint32_t m = pkMax(HS[8 * g] + both(7), HS[8 * g + 1] + both(6));
+                m = pkMax3(m, HS[8 * g + 2] + both(5), HS[8 * g + 3] + both(4));
+                m = pkMax3(m, HS[8 * g + 4] + both(3), HS[8 * g + 5] + both(2));
+                m = pkMax3(m, HS[8 * g + 6] + both(1), HS[8 * g + 7]);
+                if (inA) rowA = 8 * g + 7 - (int)(m & 7u);
+                if (inB) rowB = 8 * g + 7 - (int)((m >> 16) & 7u);
+            }
+            // of the strips' hits the smallest column wins, then the smallest row: an earlier strip's at the same column
+            if (hitA && (hA.bcol < 0 || hA.j < hA.bcol)) {
+                hA.bcol = hA.j;
+                hA.brow = hA.strip * kLanes + rowA;
+            }
+            if (hitB && (hB.bcol < 0 || hB.j < hB.bcol)) {
+                hB.bcol = hB.j;
+                hB.brow = hB.strip * kLanes + rowB;
+            }
+        }
+        // ---- a half whose strip ends here: the optimum met, or no column left that could still matter
+        const bool endA = busyA && (hitA || hA.j + 1 >= hA.need), endB = busyB && (hitB || hB.j + 1 >= hB.need);
+        if (__builtin_amdgcn_ballot_w64(endA || endB) != 0) {
+            auto finish = [&](bool end, ScanHalf& h, bool& busy, int stop) {
+                if (!end) return;
+                busy = false;
+                a.score[h.out] = h.bcol >= 0 ? stop : INT32_MIN;
+                if (a.endI) a.endI[h.out] = h.bcol >= 0 ? h.brow : -1;
+                if (a.endJ) a.endJ[h.out] = h.bcol;
+            };
+            finish(endA, hA, busyA, stopA);
+            finish(endB, hB, busyB, stopB);
+            const uint32_t idle2 = (busyA ? 0u : 0x0000ffffu) | (busyB ? 0u : 0xffff0000u);
+            tgt2 |= idle2;   // (a pattern no value reaches)
+            incr2 = (busyA ? (uint32_t)(8 * ext) : 0u) | (busyB ? (uint32_t)(8 * ext) << 16 : 0u);
+        }
+        hA.j += busyA ? 1 : 0;   // (an idle half stays where it is: its column indexes the line it reads)
+        hB.j += busyB ? 1 : 0;
+        tgt2 += incr2;
+    }
+}
+
+#include "perpair_packed_strips.inc"
+
 }  // namespace
 
 // Does the packed direction pass apply? (host side: host_full.inc)
@@ -474,6 +760,70 @@ hipError_t launchPerPairPackedTrace(const PerPairArgs& a, size_t ldsBytes, hipSt
         return four ? launchPackedTraceAs<true, 4>(a, ldsBytes, stream) : launchPackedTraceAs<true, kPkMaxWaves>(a, ldsBytes, stream);
     }
     return four ? launchPackedTraceAs<false, 4>(a, ldsBytes, stream) : launchPackedTraceAs<false, kPkMaxWaves>(a, ldsBytes, stream);
+}
+
+
+// Does the packed start-cell scan apply? (Smith-Waterman prefixes with a known optimum; host_full.inc)
+//   open >= ext >= 0, S + open + bias in [0, 31] (times 8 an unsigned byte)
+//   Z = 0x0400 + 8 (2 open + (Q + 64) ext + bias) and Z + 8 (best + longest ext) + slack <= 0x7BFF: normal half floats
+bool packedScanFits(int queryLength, int alphabet, int open, int ext, int maxScore, int minScore, int64_t longest,
+                    int64_t best, int* bias, int* zero, int* stride, size_t* ldsBytes) {
+    if (!(open >= ext && ext >= 0)) return false;
+    const int b = std::max(0, -(minScore + open));
+    if (maxScore + open + b > 31) return false;
+    // the zero: the last row's border, a bias below it, still a normal half float
+    const int64_t z = 0x0400 + 8 * (2 * (int64_t)open + ((int64_t)queryLength + kLanes) * ext + b);
+    const int64_t slack = 8 * (2 * ((int64_t)std::max(maxScore, 0) + open + ext) + b) + 8;
+    if (z + 8 * (std::max<int64_t>(best, 0) + longest * ext) + slack > 0x7BFF) return false;
+    const int pstride = perPairProfileStride(queryLength);
+    const size_t bytes = (size_t)(alphabet + 1) * pstride + 16;
+    if (bytes > 64 * 1024 || pstride > 0xfff0) return false;
+    *bias = b;
+    *zero = (int)z;
+    *stride = pstride;
+    *ldsBytes = bytes;
+    return true;
+}
+
+template <int GROUPS>
+static hipError_t launchPackedScanAs(const PerPairArgs& a, size_t ldsBytes, int blocks, hipStream_t stream) {
+    if (a.packedBias > 0)
+        hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, true>), dim3(blocks), dim3(kScanBlock), ldsBytes, stream, a);
+    else
+        hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, false>), dim3(blocks), dim3(kScanBlock), ldsBytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launchPerPairPackedScan(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream) {
+    if (a.nJobs <= 0) return hipSuccess;
+    if (a.profileStride <= 0 || !a.reversed) return hipErrorInvalidValue;
+    const int waves = (a.nJobs + 2 * kLanes - 1) / (2 * kLanes);
+    if (a.queryLength > kLanes) {
+        // several strips: a wavefront per 128 jobs of the sorted list, the rows between strips at a.boundary
+        // ([wavefront][column][lane] x 8 bytes, a.boundaryStride columns per wavefront)
+        if (a.boundary == nullptr || a.boundaryStride <= 0) return hipErrorInvalidValue;
+        const dim3 grid((waves + kScanWaves - 1) / kScanWaves), block(kScanBlock);
+        if (a.packedBias > 0) hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<true>), grid, block, ldsBytes, stream, a);
+        else hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<false>), grid, block, ldsBytes, stream, a);
+        return hipGetLastError();
+    }
+    if (a.jobCounter == nullptr || a.computeUnits <= 0) return hipErrorInvalidValue;
+    PerPairArgs b = a;
+    if (b.refillLanes <= 0) b.refillLanes = 24;
+    // persistent wavefronts: two per SIMD, three when the strip has up to 56 rows (167 registers)
+    int perCu = a.queryLength <= 56 ? 3 : 2;
+    if (const char* e = tuned(Tune::SCAN_BLOCKS_PER_CU)) perCu = std::max(1, std::min(atoi(e), 8));   // (experiments)
+    const int blocks = std::min((waves + kScanWaves - 1) / kScanWaves, a.computeUnits * perCu);
+    switch ((a.queryLength + 7) / 8) {
+        case 1: return launchPackedScanAs<1>(b, ldsBytes, blocks, stream);
+        case 2: return launchPackedScanAs<2>(b, ldsBytes, blocks, stream);
+        case 3: return launchPackedScanAs<3>(b, ldsBytes, blocks, stream);
+        case 4: return launchPackedScanAs<4>(b, ldsBytes, blocks, stream);
+        case 5: return launchPackedScanAs<5>(b, ldsBytes, blocks, stream);
+        case 6: return launchPackedScanAs<6>(b, ldsBytes, blocks, stream);
+        case 7: return launchPackedScanAs<7>(b, ldsBytes, blocks, stream);
+        default: return launchPackedScanAs<8>(b, ldsBytes, blocks, stream);
+    }
 }
 
 }  // namespace miopal
