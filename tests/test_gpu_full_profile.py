@@ -38,23 +38,51 @@ def lane_per_pair(tuning):
     tuning.setenv("MIOPAL_FORCE_LANE_PER_PAIR", "1")   # (the cost estimates prefer a wavefront per pair on few pairs)
 
 
+KEYS = ("score", "end_q", "end_t", "start_q", "start_t", "aln_off", "aln_flat")
+
+
+def packed_applies(matrix, go, ge):
+    # perpair_packed.hip (two pairs per lane, round 5): gap models with open >= ext whose scores leave room in a byte
+    return go >= ge >= 0
+
+
 def both_forms(capi, tuning, q, res, off, matrix, go, ge, algo="sw", expect_profile=True):
+    """The default routing (since round 5: two pairs per lane on 16-bit halves where the scoring scheme allows), the
+    32-bit query-profile kernels (MIOPAL_NO_PACKED_*), which must give the very same arrays, and the kernels before
+    both (MIOPAL_NO_PERPAIR_PROFILE): returns (default, before)."""
     db = capi.DeviceDatabase(res, off, 24)
     try:
         new = db.search(q, matrix, go, ge, "full", algo)
+        packed_routing = capi.DeviceDatabase.last_full_routing()
+        tuning.setenv("MIOPAL_NO_PACKED_TRACE", "1")
+        tuning.setenv("MIOPAL_NO_PACKED_SCAN", "1")
+        wide = db.search(q, matrix, go, ge, "full", algo)
         routing = capi.DeviceDatabase.last_full_routing()
+        assert routing & (64 | 128) == 0, routing
         tuning.setenv("MIOPAL_NO_PERPAIR_PROFILE", "1")
         old = db.search(q, matrix, go, ge, "full", algo)
-        assert capi.DeviceDatabase.last_full_routing() & 10 == 0
+        assert capi.DeviceDatabase.last_full_routing() & (10 | 64 | 128) == 0
         tuning.delenv("MIOPAL_NO_PERPAIR_PROFILE")
+        tuning.delenv("MIOPAL_NO_PACKED_TRACE")
+        tuning.delenv("MIOPAL_NO_PACKED_SCAN")
     finally:
         db.close()
+    for key in KEYS:
+        np.testing.assert_array_equal(new[key], wide[key], err_msg=f"{key}: packed halves against the 32-bit profile kernels")
     if expect_profile and off[-1] >= 4:
         # directions always; start cells of every mode that has a scan (NW starts at the origin); queries of one
         # strip by the persistent wavefronts that refill their lanes
         assert routing & 12 == 12, routing
         assert (routing & 3 == 3) == (algo != "nw"), routing
         assert bool(routing & 32) == (algo != "nw" and len(q) <= 64), routing
+        if packed_applies(matrix, go, ge):
+            # the direction pass of every mode, the scan of Smith-Waterman prefixes
+            # (the scan when eight times its values fit the half floats as well: not gap 5/5 against 400 columns)
+            assert packed_routing & 64, packed_routing
+            assert algo == "sw" or not packed_routing & 128, packed_routing
+            assert packed_routing & 128 or algo != "sw" or ge > 1, packed_routing
+        else:
+            assert packed_routing & (64 | 128) == 0, packed_routing
     return new, old
 
 
@@ -68,11 +96,12 @@ def test_one_strip_scan_without_refill(capi, lane_per_pair, tuning, qlen, algo):
     q = _data.random_protein(rng, qlen)
     db = capi.DeviceDatabase(res, off, 24)
     try:
+        tuning.setenv("MIOPAL_NO_PACKED_SCAN", "1")   # (the 32-bit kernels: Smith-Waterman scans take two pairs per lane otherwise)
         refill = db.search(q, B62, 3, 1, "full", algo)
-        assert capi.DeviceDatabase.last_full_routing() & 32
+        assert capi.DeviceDatabase.last_full_routing() & (32 | 128) == 32
         tuning.setenv("MIOPAL_NO_SCAN_REFILL", "1")
         plain = db.search(q, B62, 3, 1, "full", algo)
-        assert capi.DeviceDatabase.last_full_routing() & 35 == 3
+        assert capi.DeviceDatabase.last_full_routing() & (35 | 128) == 3
     finally:
         db.close()
     ref = _oracle.search(q, res, off, B62, 3, 1, "full", algo)
