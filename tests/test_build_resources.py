@@ -46,7 +46,22 @@ def test_hot_kernels_do_not_spill():
     for name in list(bad):
         if "strips_kernel" in name and bad[name].get("VGPRs Spill", 0) <= 24 and bad[name]["ScratchSize [bytes/lane]"] <= 128:
             del bad[name]
+    # The kernels with two pairs per lane (perpair_packed.hip, round 5) hold 64 rows x {H, E} of both pairs plus the
+    # flags' accumulators: a few per-strip values - pointers, lengths - sit in scratch around the column loop, not
+    # inside it (checked on the code below)
+    for name in list(bad):
+        if "perpair_packed" in name and bad[name].get("VGPRs Spill", 0) <= 24 and bad[name]["ScratchSize [bytes/lane]"] <= 128:
+            del bad[name]
     assert not bad, bad
+
+
+def test_spills_of_the_packed_pair_kernels_stay_out_of_the_column_loops():
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(CSRC), "..", "tools", "check_hot_loops.py")
+    out = subprocess.run([sys.executable, tool, "perpair_packed"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert out.stdout.count("column blocks") >= 20, out.stdout
 
 
 def test_spills_of_the_strips_kernels_stay_out_of_the_column_loops():

@@ -44,7 +44,7 @@ for tu in sys.argv[1:]:
                     cur["max3"] += 1
                 elif text.startswith("scratch_"):
                     cur["scratch"] += 1
-                if kernel and "strips_kernel" in kernel:
+                if kernel and "strips_kernel" in kernel and "perpair" not in kernel:   # (the lane-per-pair strips hand nothing over)
                     h = handover.setdefault(kernel, [0, 0, 0, 0])
                     if text.startswith(("buffer_load_dwordx4", "buffer_store_dwordx4")):
                         h[0] += 1
