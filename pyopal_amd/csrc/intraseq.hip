@@ -709,7 +709,8 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
 // none can go on. A lane that leaves its line early waits for the others; the wavefront pays a latency per line of
 // its longest path, not per step of it.
 __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
-    __shared__ uint8_t qlds[kWalkQueryLds];
+    // (the query in dynamic LDS, sized by its length: a fixed 4 KB of it cost the CU wavefronts it has registers for)
+    extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
     __shared__ uint32_t lineLds[16 * 64];   // [plane * 4 + column % 4][lane]: no two lanes share a bank
     __shared__ uint32_t resLds[5 * 64];     // the target residues of sixteen columns (five dwords: any alignment)
     for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];   // (launchWalk: the query fits)
@@ -1213,7 +1214,7 @@ hipError_t launchWalk(const WalkArgs& a, hipStream_t stream) {
         // (what the query-profile form of the direction pass guarantees: host_full.inc)
         if (a.dirWaveStride <= 0 || (a.dirStripColumns & 3) || a.opsOff || (a.opsSlot & 15) || a.queryLength > kWalkQueryLds)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(walk_planes_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(walk_planes_kernel, dim3((a.nJobs + 63) / 64), dim3(64), (size_t)((a.queryLength + 15) & ~15), stream, a);
         if (!a.headWaves) return hipGetLastError();
     }
     hipLaunchKernelGGL(walk_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);

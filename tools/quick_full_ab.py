@@ -29,7 +29,7 @@ def run(label, **switches):
         for _ in range(2):
             r = db.search(q, m, GO, GE, "full", ALGO, reuse=r)
         ts = []
-        for _ in range(5):
+        for _ in range(int(os.environ.get("REPS", "9"))):
             t0 = time.perf_counter(); r = db.search(q, m, GO, GE, "full", ALGO, reuse=r); ts.append(time.perf_counter() - t0)
         routing = _capi.DeviceDatabase.last_full_routing()
     print(f"{label:28s} Q={Q} N={N} {GO}/{GE} {ALGO}: median {np.median(ts)*1e3:8.2f} ms  min {min(ts)*1e3:8.2f}  routing {routing}", flush=True)
