@@ -172,7 +172,7 @@ inline hipError_t createUploadStream(hipStream_t* s) {
 }
 
 constexpr int kLongTarget = 8192;          // longer targets always take the intra-sequence path
-constexpr int64_t kDirBudgetOneLaunch = 32ll << 30;   // directions of every batch of a `full` search at once (host_full.inc)
+constexpr int64_t kDirBudgetOneLaunch = 8ll << 30;   // directions of every batch of a `full` search at once (host_full.inc)
 constexpr int64_t kDirBudget = 2ll << 30;  // direction workspace: 2 x this per device-resident traceback batch, 1 x per host-built batch
 constexpr int64_t kInt32Safe = 1ll << 29;
 constexpr int kMaxDirectRecompute = 2048;  // lanes that left their range and are sent straight to int32: at least this many (see directLimit)
@@ -182,7 +182,7 @@ constexpr int kMaxDirectRecompute = 2048;  // lanes that left their range and ar
 // wavefront-per-pair kernel, whose anti-diagonal step is ~10x shorter and which still has a
 // wavefront for every pair at this count.
 constexpr int64_t kSmallSearch = 4096;
-constexpr size_t kParkedWorkspaceBytes = 64ull << 30;  // idle per-handle workspaces kept at most
+constexpr size_t kParkedWorkspaceFloor = 4ull << 30;   // idle per-handle workspaces kept: this, or four times the database (host_types.inc)
 constexpr size_t kMaxCachedViews = 64;                 // packed views per handle (beside the byte budget)
 
 // malloc-backed byte buffer: grows without zero-filling, and its storage can be handed to the
@@ -425,10 +425,27 @@ void miopalReleaseCaches(void) {
         pool.freeStreams.clear();
     }
     kits.clear();
+    // (idle workspaces of every live handle)
+    std::vector<MiopalDb*> none;
+    MiopalDb::liveHandles(nullptr, 0, &none);
 }
 
-int64_t miopalDbReleaseWorkspaces(MiopalDb* db) {
-    if (!db) return 0;
+static int64_t releaseIdleWorkspaces(MiopalDb* db);
+
+
+void MiopalDb::liveHandles(MiopalDb* db, int what, std::vector<MiopalDb*>* out) {
+    static std::mutex m;
+    static std::vector<MiopalDb*> live;
+    std::lock_guard<std::mutex> g(m);
+    if (what > 0) live.push_back(db);
+    else if (what < 0) live.erase(std::remove(live.begin(), live.end(), db), live.end());
+    else if (out) {
+        // (under the lock: a handle cannot be destroyed while its idle workspaces are released)
+        for (MiopalDb* h : live) (void)releaseIdleWorkspaces(h);
+    }
+}
+
+static int64_t releaseIdleWorkspaces(MiopalDb* db) {
     std::vector<std::unique_ptr<Workspace>> idle;
     {
         std::lock_guard<std::mutex> g(db->wsMutex);
@@ -439,6 +456,11 @@ int64_t miopalDbReleaseWorkspaces(MiopalDb* db) {
     (void)hipSetDevice(db->device);
     idle.clear();   // (workspaces in use by running searches are not in the list: they come back and are kept)
     return bytes;
+}
+
+int64_t miopalDbReleaseWorkspaces(MiopalDb* db) {
+    if (!db) return 0;
+    return releaseIdleWorkspaces(db);
 }
 
 int64_t miopalDbCount(const MiopalDb* db) { return db ? db->count : 0; }
