@@ -122,6 +122,10 @@ int miopalSearchFlat(MiopalDb* db, const unsigned char* query, int queryLength, 
  * In: *operations is NULL, or a malloc'ed buffer of *operationsCapacity bytes
  * (the one an earlier call returned, its contents no longer needed). Out:
  * *operations holds the operations and *operationsCapacity its size in bytes.
+ * "Large enough" is judged against the search's WORST case - targets x (query
+ * length + longest alignment window, rounded up to 16), not against the
+ * operations it ends up producing; a buffer this library returned carries a
+ * quarter of headroom for that reason.
  * When the lent buffer is large enough the SAME pointer comes back, written in
  * place: its pages are resident already, where a fresh buffer of a million
  * alignments is 67-360 MB of first-touch page faults per search (and as much to

@@ -62,18 +62,26 @@ def align(query, database, scoring_matrix=None, *, gap_open: int = 3, gap_extend
     else:
         bounds = [0, size]
 
-    # contiguous chunks of size // chunks targets (the remainder makes one more, short chunk,
-    # as in the reference); a chunk is cut where it crosses a shard boundary
-    step = max(1, size // chunks)
     jobs = []
-    for begin in range(0, size, step):
-        stop = min(begin + step, size)
-        pieces = []
+    if not threads and devices > 1:
+        # threads=0 on several GPUs: the chunks ARE the shards (balanced by residues; chunks of size // devices
+        # targets would straddle the shard boundaries of a database with skewed lengths, each in two pieces searched
+        # one after the other by one thread)
         for d in range(devices):
-            lo, hi = max(begin, bounds[d]), min(stop, bounds[d + 1])
-            if lo < hi:
-                pieces.append((lo, hi, d, (bounds[d], bounds[d + 1]) if devices > 1 else None))
-        jobs.append(pieces)
+            if bounds[d] < bounds[d + 1]:
+                jobs.append([(bounds[d], bounds[d + 1], d, (bounds[d], bounds[d + 1]))])
+    else:
+        # contiguous chunks of size // chunks targets (the remainder makes one more, short chunk,
+        # as in the reference); a chunk is cut where it crosses a shard boundary
+        step = max(1, size // chunks)
+        for begin in range(0, size, step):
+            stop = min(begin + step, size)
+            pieces = []
+            for d in range(devices):
+                lo, hi = max(begin, bounds[d]), min(stop, bounds[d + 1])
+                if lo < hi:
+                    pieces.append((lo, hi, d, (bounds[d], bounds[d + 1]) if devices > 1 else None))
+            jobs.append(pieces)
 
     def search(pieces):
         hits = []

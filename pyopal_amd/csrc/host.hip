@@ -88,16 +88,22 @@ thread_local int g_fault[3] = {0, 0, 0};               // miopalTestInjectFault:
 // ordinal, hipSetDevice per call - on a box with one GPU)
 std::atomic<int> g_logicalDevices{0};
 
-int physicalDeviceCount() {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-    int usable = 0;
-    for (int d = 0; d < n; ++d) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ++usable;
-    }
-    return usable;
+// HIP ordinals of the gfx950 devices, in order: the only ones the kernels were built for. Device ordinals of this
+// library index THIS list (on a box with nothing but MI355X: the identity).
+const std::vector<int>& usableDevices() {
+    static const std::vector<int> list = [] {
+        std::vector<int> v;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) return v;
+        for (int d = 0; d < n; ++d) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, d) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) v.push_back(d);
+        }
+        return v;
+    }();
+    return list;
 }
+int physicalDeviceCount() { return (int)usableDevices().size(); }
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -216,6 +222,10 @@ struct HostBytes {
             data = nullptr;
             lent = false;
             want += want / 4;   // (the next search of this kind fits the buffer it gets back)
+        } else if (!data && want >= (8u << 20)) {
+            // (a first large buffer too: lent back, it is judged against the NEXT search's worst case - a query of the
+            // same length whose longest window rounds sixteen columns up must not find it too small)
+            want += want / 4;
         }
         const bool hugePages = !tuned(Tune::NO_HUGEPAGE);
         if (!data && want >= (8u << 20) && hugePages) {
@@ -885,6 +895,13 @@ int opalSearchDatabase(unsigned char query[], int queryLength, unsigned char* db
                                      searchType, mode, overflowMethod, 0, dbLength);
     }
     const auto t2 = std::chrono::steady_clock::now();
+    {
+        // view lists built ahead that no search of this call asked for (another overlap, a search that built its own
+        // before the list was ready, a loop that stopped on an error) would otherwise keep their device blocks, and
+        // stay out of handleDeviceBytes, until the handle is filled again
+        std::lock_guard<std::mutex> g(h->viewMutex);
+        h->prefetched.clear();
+    }
     if (rc == 0) {
         int64_t keepMb = 4096;
         if (const char* env = tuned(Tune::SPARE_HANDLE_MB)) keepMb = atoll(env);
