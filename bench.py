@@ -292,8 +292,64 @@ def main():
                 line["extras"] = extras(db, query, matrix, Q, N, L)
         if cfg5 is not None:
             line["extras"]["cfg5_strong"] = cfg5
-        print(json.dumps(line), flush=True)
+        print(json.dumps(compact_line(line)), flush=True)
     db.close()
+
+
+def compact_line(line, limit=8000):
+    """The ONE printed line: the contract's keys, `roofline` with one flat scalar per secondary leg (a record that keeps
+    the scalar keys of `roofline` and the last 8 KB of the line keeps every number DESIGN.md quotes), `cpu_baseline`.
+    Everything nested - per-leg and per-kernel roofline blocks, wave-cycle fractions, LDS counters, notes - goes to
+    bench_details.json beside the working directory's bench.py (and under gpurun_out/ when that exists)."""
+    ex = line.pop("extras", {}) or {}
+    roof = line["roofline"]
+    details = {"roofline": {k: roof.pop(k) for k in ("valu_issue", "lds") if k in roof}, "extras": ex,
+               "value": line["value"], "ms_per_step": line["ms_per_step"], "library_sha256": library_sha256()}
+    valu = details["roofline"].get("valu_issue") or {}
+    flat = {
+        "valu_issue_frac": valu.get("frac"), "valu_instructions_per_cell_pair": valu.get("instructions_per_cell_pair"),
+        "pageable_gcups": line.get("value_host_results_pageable"), "device_results_gcups": line.get("value_device_results"),
+        "pcie_inclusive_ms": line.get("ms_per_step_pcie_inclusive"), "pcie_inclusive_gcups": line.get("value_pcie_inclusive"),
+    }
+
+    def get(*path):
+        d = ex
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    flat.update({
+        "sustained_median_ms": get("sustained", "ms_per_search", "median"), "sustained_p99_ms": get("sustained", "ms_per_search", "p99"),
+        "lognormal_gcups": get("lognormal_lengths", "host_results_gcups"),
+        "cfg2_end_ms": get("cfg2_end", "ms"), "cfg3_full_ms": get("cfg3_full", "ms"),
+        "cfg3_full_operations": get("cfg3_full", "alignment_operations"),
+        "q150_score_ms": get("longer_queries_sw", "q150", "score", "ms"), "q150_end_ms": get("longer_queries_sw", "q150", "end", "ms"),
+        "q300_score_ms": get("longer_queries_sw", "q300", "score", "ms"), "q300_end_ms": get("longer_queries_sw", "q300", "end", "ms"),
+        "q300_full_ms": get("longer_queries_sw", "q300", "full", "ms"),
+        "cfg4_nw_ms": get("cfg4_with_tail", "nw", "ms"), "cfg4_hw_ms": get("cfg4_with_tail", "hw", "ms"),
+        "cfg4_ov_ms": get("cfg4_with_tail", "ov", "ms"), "cfg4_sw_ms": get("cfg4_with_tail", "sw", "ms"),
+        "cfg4_nw_gcups": get("cfg4_with_tail", "nw", "host_results_gcups"),
+        "cfg5_gcups": get("cfg5_strong", "gcups"), "cfg5_ms": get("cfg5_strong", "ms_per_step"),
+    })
+    roof.update({k: v for k, v in flat.items() if v is not None})
+    line["details_file"] = "bench_details.json"
+    for where in (os.getcwd(), os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(where):
+                with open(os.path.join(where, "bench_details.json"), "w") as f:
+                    json.dump(details, f, indent=1)
+        except OSError:
+            pass
+    # (never beyond the limit: the longest strings go first)
+    for key in ("note", "traffic_source"):
+        if len(json.dumps(line)) > limit and key in roof:
+            roof[key] = roof[key][:80]
+    if len(json.dumps(line)) > limit and isinstance(line.get("cpu_baseline"), dict):
+        for key in ("note", "sample", "cpu"):
+            if len(json.dumps(line)) > limit and isinstance(line["cpu_baseline"].get(key), str):
+                line["cpu_baseline"][key] = line["cpu_baseline"][key][:120]
+    return line
 
 
 def device_results(db, query, matrix, out, stream, Q, N, L):
@@ -427,11 +483,13 @@ def full_pipeline_roofline(res, Q, N, L, wall_ms, alg_bytes_whole):
     window_cols = float((end_t[live] - start_t[live] + 1).sum())
     window_cells = float(((end_t[live] - start_t[live] + 1) * (end_q[live] - start_q[live] + 1)).sum())
     batches = 4.0
+    groups = 2.0   # (round 5: the direction pass of two batches per launch)
     stages = [
         ("end pass (scores + end cells)", "cfg3full_interseq_pair_biased_kernel", 1.0, float(N) * L + 20.0 * N),
-        ("start cells: scan of the reversed prefixes", "cfg3full_perpair_scan_refill_kernel", 1.0, prefix_residues + 28.0 * N),
-        ("directions of the [start..end] rectangles (4 bits a cell)", "cfg3full_perpair_profile_kernel", batches,
-         (window_cols + 0.5 * window_cells + 60.0 * N) / batches),
+        ("start cells: scan of the reversed prefixes, two pairs per lane", "cfg3full_perpair_packed_scan_kernel", 1.0,
+         prefix_residues + 28.0 * N),
+        ("directions of the [start..end] rectangles (4 bits a cell), two pairs per lane", "cfg3full_perpair_packed_trace_kernel", groups,
+         (window_cols + 0.5 * window_cells + 60.0 * N) / groups),
         ("walk: operations from the direction bits", "cfg3full_walk_planes_kernel", batches, (2.5 * ops + 60.0 * N) / batches),
         ("operations compacted into slice order", "cfg3full_gather_ops_kernel", batches, (2.0 * ops + 12.0 * N) / batches),
         ("operations to pinned host memory, two bits each", "cfg3full_copy_out_packed_kernel", batches, 1.25 * ops / batches),
@@ -453,8 +511,8 @@ def full_pipeline_roofline(res, Q, N, L, wall_ms, alg_bytes_whole):
     return {"bound": "hbm", "kernel": "pipeline (see kernels)", "kernel_ms": round(wall_ms, 4), "algorithmic_bytes": alg_bytes_whole,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "note": "kernel_ms / achieved of this block: wall time of the whole call (host-visible results); per kernel below. "
-                    "The direction and scan passes are VALU-issue-bound (14 / 6.5 instructions per cell at 32 bit), the walk by "
-                    "memory latency (one round trip per 64-byte line of direction bits and wavefront)",
+                    "The direction and scan passes are VALU-issue-bound (two pairs per lane on 16-bit halves: 8 / 4.5 instructions "
+                    "per cell), the walk by memory latency (one round trip per 64-byte line of direction bits and wavefront)",
             "kernels": kernels}
 
 
@@ -742,16 +800,18 @@ def extras(db, query, matrix, Q, N, L):
         dt, k_ms, routing, res = timed_leg(db, q300, "full", "sw", 3)
         stages = []
         for what, tag, launches in (("end pass", "q300full_interseq_pair_strips_kernel", 1),
-                                    ("start cells: scan of the reversed prefixes", "q300full_perpair_profile_kernel_3", 1),
-                                    ("directions (4 bits a cell)", "q300full_perpair_profile_kernel_4", 8),
-                                    ("walk", "q300full_walk_planes_kernel", 8)):
+                                    ("start cells: scan of the reversed prefixes, two pairs per lane", "q300full_perpair_packed_scan_strips_kernel", 1),
+                                    ("directions (4 bits a cell), two pairs per lane", "q300full_perpair_packed_trace_kernel", 4),
+                                    ("walk", "q300full_walk_planes_kernel", 4),
+                                    ("operations to pinned host memory, two bits each", "q300full_copy_out_packed_kernel", 4)):
             pmc = pmc_summary(tag)
             stages.append({"stage": what, "launches_per_search": launches,
                            "kernel_ms": round(pmc["kernel_ms"], 3) if pmc and pmc.get("kernel_ms") else None,
                            "source": pmc["file"] if pmc else None})
         out["longer_queries_sw"]["q300"]["full"] = {"ms": round(dt * 1e3, 2), "host_results_gcups": round(300.0 * N * L / dt / 1e9, 1),
                        "alignment_operations": int(res["aln_off"][-1]), "kernels": stages,
-                       "note": "VALU-issue-bound passes at 32 bit (8.1 / 15 instructions per cell): DESIGN.md section 7"}
+                       "note": "VALU-issue-bound passes, two pairs per lane on 16-bit halves since round 5 (4.5 / 8 instructions per "
+                               "cell; 8.1 / 15 at 32 bit before): DESIGN.md section 4"}
         del res
     # BASELINE configs[3] as written: 2000-aa query vs 100k x 2000 PLUS the reference's 35 long targets
     # (1000 ... 35000 residues: the ones that really leave 16 bits), every algorithm, scores
