@@ -444,8 +444,10 @@ static int64_t releaseIdleWorkspaces(MiopalDb* db);
 
 
 void MiopalDb::liveHandles(MiopalDb* db, int what, std::vector<MiopalDb*>* out) {
-    static std::mutex m;
-    static std::vector<MiopalDb*> live;
+    // (never destroyed: handles parked in the spare pool are destroyed at exit, after function-local statics of
+    // this kind would have been)
+    static std::mutex& m = *new std::mutex;
+    static std::vector<MiopalDb*>& live = *new std::vector<MiopalDb*>;
     std::lock_guard<std::mutex> g(m);
     if (what > 0) live.push_back(db);
     else if (what < 0) live.erase(std::remove(live.begin(), live.end(), db), live.end());
@@ -463,6 +465,12 @@ static int64_t releaseIdleWorkspaces(MiopalDb* db) {
     }
     int64_t bytes = 0;
     for (const auto& w : idle) bytes += (int64_t)w->bytes();
+    {
+        // (the kernel timings of the last profiled search live in its workspace: miopalLastKernelTime)
+        std::lock_guard<std::mutex> g(db->timingMutex);
+        for (const auto& w : idle)
+            if (db->lastTimed == w.get()) db->lastTimed = nullptr;
+    }
     (void)hipSetDevice(db->device);
     idle.clear();   // (workspaces in use by running searches are not in the list: they come back and are kept)
     return bytes;

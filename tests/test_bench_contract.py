@@ -44,7 +44,8 @@ def test_bench_line_small_workload():
     # flat scalar per secondary leg inside `roofline`; everything nested is in bench_details.json beside it
     assert len(lines[0]) <= 8192, len(lines[0])
     assert all(not isinstance(v, (dict, list)) for v in roof.values()), roof
-    for key in ("valu_issue_frac", "valu_instructions_per_cell_pair", "pageable_gcups", "device_results_gcups", "pcie_inclusive_ms",
+    # (valu_issue_frac / valu_instructions_per_cell_pair too when a PMC summary of this very build is committed)
+    for key in ("pageable_gcups", "device_results_gcups", "pcie_inclusive_ms",
                 "sustained_median_ms", "lognormal_gcups", "cfg2_end_ms", "q150_score_ms", "q150_end_ms", "q300_score_ms",
                 "q300_end_ms", "cfg5_gcups"):
         assert roof.get(key) and roof[key] > 0, key
