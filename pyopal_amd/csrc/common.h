@@ -185,6 +185,17 @@ struct PerPairArgs {
     // perpair_packed_scan_kernel / perpair_packed_scan_strips_kernel (the latter's rows between strips: `boundary`,
     // [job / 128][column][lane] x 8 bytes)
     int packedZero;           // pattern of the value 0 (packedScanFits)
+    // The packed scans of a Smith-Waterman search write the START CELLS themselves (no reverse-pass arrays, no
+    // start_cells_kernel behind them): startQ / startT by job.out, startChecks = {1 + index of a pair whose scan never met
+    // its optimum, longest target window, tallest query window} (zeroed by the host). And the one-strip scan builds its
+    // jobs from the end pass's arrays (slice order; jobs == nullptr): no job list in HBM.
+    int32_t* startQ;
+    int32_t* startT;
+    int* startChecks;
+    const int32_t* fwdScore;
+    const int32_t* fwdEndQ;
+    const int32_t* fwdEndT;
+    const int64_t* fwdOffsets;
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 // perpair_packed.hip: the direction pass with two pairs per lane. packedTraceFits says whether it applies (rows /

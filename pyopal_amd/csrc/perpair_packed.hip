@@ -501,6 +501,8 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
     int LA = 0, LB = 0;
     int stopA = 0, stopB = 0;
 
+    int windowMax = 0, rowsMax = 0;   // (with start cells: the longest target window and tallest query window seen)
+
     for (int w = 0;; ++w) {
         if ((w & 3) == 0) {
             // ---- service: halves that go on to their pair's next strip, halves that take a new pair
@@ -521,7 +523,21 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                                       __builtin_amdgcn_mbcnt_hi((uint32_t)(maskB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)maskB, 0));
                     auto take = [&](bool want, int k, ScanHalf& h, int& L, int& stop, bool& start) {
                         if (!want || k >= a.nJobs) return;
-                        const PairJob job = a.jobs[k];
+                        PairJob job{};
+                        if (a.jobs != nullptr) {
+                            job = a.jobs[k];
+                        } else {
+                            // the reversed prefixes anchored on the end cell, straight from the end pass's arrays
+                            const int qe = a.fwdEndQ[k], te = a.fwdEndT[k];
+                            job.out = k;
+                            job.stop = a.fwdScore[k];
+                            if (qe >= 0 && te >= 0) {
+                                job.tOff = a.fwdOffsets[k] + te;
+                                job.tLen = te + 1;
+                                job.qOff = qe;
+                                job.qLen = qe + 1;
+                            }
+                        }
                         h.Q = job.qLen;
                         L = job.tLen;
                         h.need = L;
@@ -533,6 +549,9 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                         h.bcol = h.brow = -1;
                         if (job.qLen > 0 && job.tLen > 0) {
                             start = true;
+                        } else if (a.startQ != nullptr) {
+                            a.startQ[job.out] = -1;   // (no end cell: no alignment)
+                            a.startT[job.out] = -1;
                         } else {
                             // degenerate pair: closed forms of the border (oracle/opal_oracle.c, dp_pass)
                             int v = 0;
@@ -673,15 +692,27 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
         // ---- a half whose strip ends here: the optimum met, or no column left that could still matter
         const bool endA = busyA && (hitA || hA.j + 1 >= hA.need), endB = busyB && (hitB || hB.j + 1 >= hB.need);
         if (__builtin_amdgcn_ballot_w64(endA || endB) != 0) {
-            auto finish = [&](bool end, ScanHalf& h, bool& busy, int stop) {
+            auto finish = [&](bool end, ScanHalf& h, bool& busy, int stop, int L) {
                 if (!end) return;
                 busy = false;
+                if (a.startQ != nullptr) {
+                    // the start cell (what start_cells_kernel makes of the reverse pass: intraseq.hip); a scan that never
+                    // met the optimum of the forward pass is reported, its window is the whole prefix
+                    const bool found = h.bcol >= 0;
+                    if (!found) atomicExch(a.startChecks, h.out + 1);
+                    const int sq = found ? h.Q - 1 - h.brow : 0, st = found ? L - 1 - h.bcol : 0;
+                    a.startQ[h.out] = sq;
+                    a.startT[h.out] = st;
+                    windowMax = max(windowMax, L - st);
+                    rowsMax = max(rowsMax, h.Q - sq);
+                    return;
+                }
                 a.score[h.out] = h.bcol >= 0 ? stop : INT32_MIN;
                 if (a.endI) a.endI[h.out] = h.bcol >= 0 ? h.brow : -1;
                 if (a.endJ) a.endJ[h.out] = h.bcol;
             };
-            finish(endA, hA, busyA, stopA);
-            finish(endB, hB, busyB, stopB);
+            finish(endA, hA, busyA, stopA, LA);
+            finish(endB, hB, busyB, stopB, LB);
             const uint32_t idle2 = (busyA ? 0u : 0x0000ffffu) | (busyB ? 0u : 0xffff0000u);
             tgt2 |= idle2;   // (a pattern no value reaches)
             incr2 = (busyA ? (uint32_t)(8 * ext) : 0u) | (busyB ? (uint32_t)(8 * ext) << 16 : 0u);
@@ -689,6 +720,18 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
         hA.j += busyA ? 1 : 0;   // (an idle half stays where it is: its column indexes the line it reads)
         hB.j += busyB ? 1 : 0;
         tgt2 += incr2;
+    }
+    if (a.startQ != nullptr) {
+        // the slots of the traceback are sized by these two: one pair of atomics per wavefront
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            windowMax = max(windowMax, __shfl_xor(windowMax, off));
+            rowsMax = max(rowsMax, __shfl_xor(rowsMax, off));
+        }
+        if (lane == 0 && windowMax > 0) {
+            atomicMax(a.startChecks + 1, windowMax);
+            atomicMax(a.startChecks + 2, rowsMax);
+        }
     }
 }
 
@@ -801,15 +844,18 @@ hipError_t launchPerPairPackedScan(const PerPairArgs& a, size_t ldsBytes, hipStr
     if (a.queryLength > kLanes) {
         // several strips: a wavefront per 128 jobs of the sorted list, the rows between strips at a.boundary
         // ([wavefront][column][lane] x 8 bytes, a.boundaryStride columns per wavefront)
-        if (a.boundary == nullptr || a.boundaryStride <= 0) return hipErrorInvalidValue;
+        if (a.boundary == nullptr || a.boundaryStride <= 0 || a.jobs == nullptr) return hipErrorInvalidValue;
         const dim3 grid((waves + kScanWaves - 1) / kScanWaves), block(kScanBlock);
         if (a.packedBias > 0) hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<true>), grid, block, ldsBytes, stream, a);
         else hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<false>), grid, block, ldsBytes, stream, a);
         return hipGetLastError();
     }
     if (a.jobCounter == nullptr || a.computeUnits <= 0) return hipErrorInvalidValue;
+    if (a.jobs == nullptr && (!a.fwdScore || !a.fwdEndQ || !a.fwdEndT || !a.fwdOffsets)) return hipErrorInvalidValue;
+    if (a.startQ != nullptr && (!a.startT || !a.startChecks)) return hipErrorInvalidValue;
     PerPairArgs b = a;
     if (b.refillLanes <= 0) b.refillLanes = 24;
+    if (const char* e = tuned(Tune::SCAN_REFILL_LANES)) b.refillLanes = std::min(128, std::max(1, atoi(e)));   // (experiments)
     // persistent wavefronts: two per SIMD, three when the strip has up to 56 rows (167 registers)
     int perCu = a.queryLength <= 56 ? 3 : 2;
     if (const char* e = tuned(Tune::SCAN_BLOCKS_PER_CU)) perCu = std::max(1, std::min(atoi(e), 8));   // (experiments)
