@@ -25,8 +25,10 @@ bad = 0
 for tu in sys.argv[1:]:
     work = tempfile.mkdtemp(prefix="hotloops_")
     try:
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
-                        f"-I{CSRC}", "--save-temps", "-c", os.path.join(CSRC, tu + ".hip"), "-o", os.path.join(work, "x.o")],
+        # (the flags of pyopal_amd/csrc/Makefile: perpair_packed.o is scheduled for instruction-level parallelism)
+        extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"] if tu == "perpair_packed" else []
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function"] + extra +
+                       [f"-I{CSRC}", "--save-temps", "-c", os.path.join(CSRC, tu + ".hip"), "-o", os.path.join(work, "x.o")],
                        cwd=work, check=True, stderr=subprocess.DEVNULL)
         asm = [f for f in os.listdir(work) if f.endswith("gfx950.s")][0]
         kernel, blocks, cur = None, [], None
