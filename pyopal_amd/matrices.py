@@ -138,7 +138,14 @@ class ScoringMatrix:
             wanted = {name.lower(), name.lower() + ".txt", name.lower() + ".mat"}
             for entry in sorted(entries):
                 if entry.lower() in wanted:
-                    return cls.from_file(os.path.join(directory, entry), name=name)
+                    # (a digest beside the table - "<file>.sha256", the first word of it - is enforced)
+                    digest = None
+                    try:
+                        with open(os.path.join(directory, entry + ".sha256")) as f:
+                            digest = f.read().split()[0]
+                    except (OSError, IndexError):
+                        pass
+                    return cls.from_file(os.path.join(directory, entry), name=name, sha256=digest)
         known = " (a name of the scoring-matrices package)" if name.upper() in _KNOWN_ELSEWHERE else ""
         raise ValueError(
             f"unknown scoring matrix: {name!r}{known}; built in: {', '.join(sorted(_TABLES))}. Load an "
@@ -146,12 +153,24 @@ class ScoringMatrix:
             "PYOPAL_AMD_MATRIX_PATH, or install scoring-matrices")
 
     @classmethod
-    def from_file(cls, file, name: typing.Optional[str] = None) -> "ScoringMatrix":
+    def from_file(cls, file, name: typing.Optional[str] = None, sha256: typing.Optional[str] = None) -> "ScoringMatrix":
         """Load a matrix in the NCBI text format (``#`` comments, a header line of
-        column letters, then one row per letter). `file` is a path or a file object."""
+        column letters, then one row per letter). `file` is a path or a file object.
+
+        ``sha256``: the hex digest the file's bytes must have (a path only) - a deployment that ships the NCBI
+        tables this package does not carry (VTML, PAM, the rest of BLOSUM: see `from_name`) pins them this way;
+        a table that differs by one entry raises ``ValueError`` instead of scoring differently."""
         if isinstance(file, (str, bytes)) or hasattr(file, "__fspath__"):
+            if sha256 is not None:
+                import hashlib
+                with open(file, "rb") as raw:
+                    digest = hashlib.sha256(raw.read()).hexdigest()
+                if digest.lower() != sha256.strip().lower():
+                    raise ValueError(f"{file}: sha256 {digest} differs from the expected {sha256}")
             with open(file) as handle:
                 return cls.from_file(handle, name=name)
+        if sha256 is not None:
+            raise ValueError("sha256 can only be checked for a path")
         letters = None
         rows = []
         row_letters = []

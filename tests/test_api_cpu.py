@@ -267,3 +267,30 @@ def test_matrix_names_beyond_the_built_in_tables(tmp_path, monkeypatch):
     assert m[letters.index("W"), letters.index("W")] == 12
     aligner = pyopal.Aligner("VTML80")
     assert aligner.scoring_matrix == m and aligner.alphabet == pyopal.Alphabet(letters)
+
+
+def test_matrix_files_pinned_by_their_digest(tmp_path, monkeypatch):
+    # a deployment that ships the NCBI tables this package does not carry pins them: from_file(path, sha256=...)
+    # and a "<file>.sha256" beside a table found through PYOPAL_AMD_MATRIX_PATH; one changed entry is refused
+    import hashlib
+    from pyopal_amd.matrices import ScoringMatrix
+    b62 = ScoringMatrix.from_name("BLOSUM62")
+    letters = b62.alphabet
+    text = "   " + "  ".join(letters) + "\n" + "".join(
+        letter + " " + " ".join(str(int(x)) for x in row) + "\n" for letter, row in zip(letters, b62.matrix))
+    path = tmp_path / "pam250.mat"
+    path.write_text(text)
+    digest = hashlib.sha256(text.encode()).hexdigest()
+    assert ScoringMatrix.from_file(path, sha256=digest) == b62
+    assert ScoringMatrix.from_file(str(path), sha256=digest.upper()) == b62
+    with pytest.raises(ValueError, match="sha256"):
+        ScoringMatrix.from_file(path, sha256="0" * 64)
+    with pytest.raises(ValueError, match="path"):
+        with open(path) as handle:
+            ScoringMatrix.from_file(handle, sha256=digest)
+    monkeypatch.setenv("PYOPAL_AMD_MATRIX_PATH", str(tmp_path))
+    (tmp_path / "pam250.mat.sha256").write_text(digest + "  pam250.mat\n")
+    assert ScoringMatrix.from_name("PAM250") == b62
+    path.write_text(text.replace(" 11 ", " 12 ", 1))     # W/W of BLOSUM62
+    with pytest.raises(ValueError, match="sha256"):
+        ScoringMatrix.from_name("PAM250")
