@@ -176,9 +176,13 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
     // strip boundaries of the wavefront: (stored H, F before it met that H) of the strip's last row, per column
     uint2* bnd = a.boundary ? reinterpret_cast<uint2*>(a.boundary) + (int64_t)W * a.boundaryStride * kLanes + lane : nullptr;
     // lines of the two pairs: [pair / 64][strip][column / 4][rows 0-31 | 32-63][pair % 64][column % 4][plane]
-    uint8_t* const dirsA = a.dirs + (int64_t)(idxA >> 6) * a.dirWaveStride + lane * 64;
-    uint8_t* const dirsB = a.dirs + (int64_t)(idxB >> 6) * a.dirWaveStride + lane * 64;
-    uint4* const stage = stageAll + wave * (kPkStageBytes / 16) + lane;   // [column % 4][line][lane]
+    uint8_t* const waveDirsA = a.dirs + (int64_t)(W * 2) * a.dirWaveStride;        // (wave-uniform: the lines of pair 0 of either half)
+    uint8_t* const waveDirsB = a.dirs + (int64_t)(W * 2 + 1) * a.dirWaveStride;
+    uint4* const stageWave = stageAll + wave * (kPkStageBytes / 16);      // [column % 4][line][pair of the half]
+    uint4* const stage = stageWave + lane;
+    // pairs of either half whose lines are written (none of a half left to intraseq_kernel, or beyond the list)
+    const int liveA = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(activeA)));
+    const int liveB = __builtin_amdgcn_readfirstlane(__builtin_popcountll(__builtin_amdgcn_ballot_w64(activeB)));
 
     // deposit masks: row r of a group of eight -> bit 15 - r of either half
     // (wave-uniform constants: the compiler keeps them in SGPRs, one per v_bfi)
@@ -200,8 +204,8 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
             uint32_t HS[ROWS], E[ROWS];
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) HS[i] = E[i] = top2;   // column -1
-            uint8_t* const stripA = dirsA + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
-            uint8_t* const stripB = dirsB + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
+            uint8_t* const waveStripA = waveDirsA + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
+            uint8_t* const waveStripB = waveDirsB + (int64_t)s * a.dirStripColumns * (kLanes / 2 * kLanes);
             // the cell above-left of the strip's first cell: the origin (value 0 two steps up the scale) or a border cell
             uint32_t aboveHsPrev = s == 0 ? both(kPkZero - 2 * ext - c) : top2;
             const int lastLocalA = QA - 1 - row0, lastLocalB = QB - 1 - row0;
@@ -336,27 +340,21 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
                 prowB = prowNextB;
                 if (ROWS == kLanes && toNext && j < maxL) bnd[(int64_t)j * kLanes] = make_uint2(HS[ROWS - 1], fOldLast);
                 if ((j & 3) == 3) {
-                    // block of four columns: the lane's lines leave for HBM whole, 64 bytes each
+                    // Block of four columns: the staged lines leave for HBM. Every store instruction writes 1 KB in one
+                    // piece - lane l the 16 bytes of column l % 4 of pair 16 k + l / 4 - i.e. whole 128-byte lines. (A lane
+                    // writing its own line, 16 bytes an instruction, touched 64 lines per instruction, a quarter of a
+                    // half each: the L2 fetched every line it was handed a piece of - FETCH_SIZE as large as WRITE_SIZE.)
                     const int64_t blockOff = (int64_t)(j >> 2) * (2 * kLanes * 64);
+                    const int x = lane & 3, sub = lane >> 2;
 #pragma unroll
                     for (int hs = 0; hs < (ROWS > 32 ? 2 : 1); ++hs) {
-                        uint4* const toA = reinterpret_cast<uint4*>(stripA + blockOff + hs * (kLanes * 64));
-                        uint4* const toB = reinterpret_cast<uint4*>(stripB + blockOff + hs * (kLanes * 64));
-                        // (one line at a time: sixteen reads in flight at once would take 64 registers)
-                        {
-                            const uint4 v0 = stage[(0 * 4 + hs) * kLanes], v1 = stage[(1 * 4 + hs) * kLanes],
-                                        v2 = stage[(2 * 4 + hs) * kLanes], v3 = stage[(3 * 4 + hs) * kLanes];
-                            if (activeA) {
-                                toA[0] = v0; toA[1] = v1; toA[2] = v2; toA[3] = v3;
-                            }
-                        }
-                        asm volatile("" ::: "memory");
-                        {
-                            const uint4 v0 = stage[(0 * 4 + 2 + hs) * kLanes], v1 = stage[(1 * 4 + 2 + hs) * kLanes],
-                                        v2 = stage[(2 * 4 + 2 + hs) * kLanes], v3 = stage[(3 * 4 + 2 + hs) * kLanes];
-                            if (activeB) {
-                                toB[0] = v0; toB[1] = v1; toB[2] = v2; toB[3] = v3;
-                            }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int pr = 16 * k + sub;   // pair of its half of the wavefront
+                            const uint4 va = stageWave[(x * 4 + hs) * kLanes + pr];
+                            const uint4 vb = stageWave[(x * 4 + 2 + hs) * kLanes + pr];
+                            if (pr < liveA) *reinterpret_cast<uint4*>(waveStripA + blockOff + hs * (kLanes * 64) + pr * 64 + x * 16) = va;
+                            if (pr < liveB) *reinterpret_cast<uint4*>(waveStripB + blockOff + hs * (kLanes * 64) + pr * 64 + x * 16) = vb;
                         }
                         asm volatile("" ::: "memory");
                     }
