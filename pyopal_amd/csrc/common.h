@@ -325,12 +325,14 @@ hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_
                            const int32_t* endT, const int64_t* offsets, int64_t dirStride, int64_t wsStride,
                            PairJob* jobs, hipStream_t stream);
 // Counting sort by tLen, longest first (lengths are coarsened so that at most 8192 bins are needed).
-// bins: min(maxLen, 8191) + 1 ints.
+// queryRows > 8: the window's rows in groups of eight as a minor key, tallest first (what a direction wavefront
+// sweeps is its tallest window times its longest). bins: 8192 ints.
 // headWaves (optional): receives how many leading wavefronts of 64 sorted jobs are outliers - more
 // than twice as long as the 90th percentile - capped at maxHeadWaves: a lane-per-pair wavefront
 // lasts as long as its longest lane, those few go to the wavefront-per-pair kernel instead.
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
-                                  hipStream_t stream, int* headWaves = nullptr, int maxHeadWaves = 0);
+                                  hipStream_t stream, int* headWaves = nullptr, int maxHeadWaves = 0,
+                                  int queryRows = 0);
 // blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
                            int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,

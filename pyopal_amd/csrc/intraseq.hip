@@ -1019,20 +1019,35 @@ constexpr int kSortBlock = 1024;
 constexpr int kSortMaxBins = 8192;  // 32 KB of LDS
 
 // (keys are lengths >> shift, so that windows of any length sort with at most 8192 bins)
+// Round 5: a second, minor key - the window's ROWS in groups of eight. A direction wavefront sweeps the rows of its
+// tallest window times the columns of its longest for all of its pairs; by length alone 82 % (cfg3) to 59 % (short
+// alignments) of the swept cells belong to a pair, with the rows as a minor key 89 % to 76 %
+// (profiles/r05_sweep_efficiency.txt). SortKey{shift, G, rowShift}: key = (tLen >> shift) * G + rows-of-eight >> rowShift;
+// G = 1 is the sort by length alone. maxKey is the largest key.
+struct SortKey {
+    int shift, groups, rowShift;
+    __device__ __forceinline__ int of(const PairJob& j, int maxKey) const {
+        const int lenKey = j.tLen >> shift;
+        if (groups == 1) return min(lenKey, maxKey);
+        const int rows = min(groups - 1, ((j.qLen + 7) >> 3) >> rowShift);
+        return min(lenKey * groups + rows, maxKey);
+    }
+};
+
 __global__ __launch_bounds__(kSortBlock) void job_length_histogram_kernel(const PairJob* jobs, int n, int maxLen,
-                                                                          int shift, int* bins) {
+                                                                          SortKey sk, int* bins) {
     extern __shared__ int local[];
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
     __syncthreads();
     for (int k = blockIdx.x * kSortBlock + threadIdx.x; k < n; k += gridDim.x * kSortBlock)
-        atomicAdd(&local[min(jobs[k].tLen >> shift, maxLen)], 1);
+        atomicAdd(&local[sk.of(jobs[k], maxLen)], 1);
     __syncthreads();
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock)
         if (local[b]) atomicAdd(&bins[b], local[b]);
 }
 
 // bins[b] <- first position of length b in the sorted order (lengths descending); one block
-__global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxLen, int* bins, int n, int shift,
+__global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxLen, int* bins, int n, SortKey sk,
                                                                         int* headWaves, int maxHeadWaves) {
     __shared__ int partial[kSortBlock];
     const int nBins = maxLen + 1;
@@ -1069,9 +1084,10 @@ __global__ __launch_bounds__(kSortBlock) void job_length_offsets_kernel(int maxL
         if (mine < maxLen) atomicMin(&p90Shared, mine);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int p90 = p90Shared;
-            const int floorKey = 64 >> shift;
-            const int longKey = max(2 * p90, floorKey) + 1;      // outliers have key >= longKey
+            // (in length keys: the rows are the minor key)
+            const int p90 = p90Shared / sk.groups;
+            const int floorKey = 64 >> sk.shift;
+            const int longKey = (max(2 * p90, floorKey) + 1) * sk.groups;      // outliers have key >= longKey
             int count = 0;
             if (longKey <= maxLen) count = longKey >= 1 ? bins[longKey - 1] : n;
             *headWaves = min((count + kLanes - 1) / kLanes, maxHeadWaves);
@@ -1087,7 +1103,7 @@ constexpr int kJobWords = sizeof(PairJob) / 4;
 static_assert(sizeof(PairJob) % 4 == 0, "PairJob is copied as dwords");
 
 __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const PairJob* jobs, int n, int maxLen,
-                                                                        int shift, int* bins, PairJob* sorted) {
+                                                                        SortKey sk, int* bins, PairJob* sorted) {
     extern __shared__ int local[];
     __shared__ int dest[kSortBlock];
     for (int b = threadIdx.x; b <= maxLen; b += kSortBlock) local[b] = 0;
@@ -1096,7 +1112,7 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
     const int64_t k = base + threadIdx.x;
     int key = 0, rank = 0;
     if (k < n) {
-        key = min(jobs[k].tLen >> shift, maxLen);
+        key = sk.of(jobs[k], maxLen);
         rank = atomicAdd(&local[key], 1);
     }
     __syncthreads();
@@ -1117,20 +1133,26 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
 }
 
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
-                                  hipStream_t stream, int* headWaves, int maxHeadWaves) {
+                                  hipStream_t stream, int* headWaves, int maxHeadWaves, int queryRows) {
     if (n <= 0) return hipSuccess;
-    int shift = 0;
-    while ((maxLen >> shift) >= kSortMaxBins) ++shift;
-    const int maxKey = maxLen >> shift;
+    SortKey sk{0, 1, 0};
+    if (queryRows > 8) {
+        // rows of eight as the minor key; lengths in steps of four (the columns a wavefront sweeps are)
+        sk.groups = (queryRows + 7) / 8 + 1;
+        while (sk.groups > 64) { sk.groups = (sk.groups + 1) / 2; ++sk.rowShift; }
+        sk.shift = 2;
+    }
+    while (((int64_t)(maxLen >> sk.shift) + 1) * sk.groups > kSortMaxBins) ++sk.shift;
+    const int maxKey = (maxLen >> sk.shift) * sk.groups + sk.groups - 1;
     hipError_t e = hipMemsetAsync(bins, 0, (size_t)(maxKey + 1) * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int blocks = std::min((n + kSortBlock - 1) / kSortBlock, 1024);
     hipLaunchKernelGGL(job_length_histogram_kernel, dim3(blocks), dim3(kSortBlock),
-                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins);
-    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins, n, shift,
+                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, sk, bins);
+    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins, n, sk,
                        headWaves, maxHeadWaves);
     hipLaunchKernelGGL(job_length_scatter_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
-                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, shift, bins, sorted);
+                       (size_t)(maxKey + 1) * sizeof(int), stream, jobs, n, maxKey, sk, bins, sorted);
     return hipGetLastError();
 }
 

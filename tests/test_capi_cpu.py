@@ -126,6 +126,12 @@ def test_tuning_switches_are_arguments_not_environment(capi, monkeypatch):
             text = open(os.path.join(src, name)).read()
             calls += [(name, m.start()) for m in re.finditer(r"\bgetenv\s*\(", re.sub(r"//.*", "", text))]
     assert [c[0] for c in calls] == ["host.hip"], calls             # Tuning::fromEnv, and nothing else
+    # the table of switches in INTEGRATION.md is the list of tuning.h, name by name, and the library knows each
+    listed = re.findall(r"X\(([A-Z_0-9]+)\)", open(os.path.join(src, "tuning.h")).read().split("enum class Tune")[0])
+    documented = re.findall(r"^\| `([A-Z_0-9]+)` \|", open(os.path.join(ROOT, "INTEGRATION.md")).read(), re.M)
+    assert sorted(listed) == sorted(documented), set(listed) ^ set(documented)
+    for name in listed:
+        assert capi.lib().miopalSetTuning(name.encode(), capi.get_tuning(name).encode() if capi.get_tuning(name) else None) == 0, name
 
 
 def test_logical_devices_hook_needs_a_physical_device(capi):
