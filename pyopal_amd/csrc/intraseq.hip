@@ -708,10 +708,21 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
 // round trip for the whole wavefront - then all lanes step through what they hold, a few cycles a step, until
 // none can go on. A lane that leaves its line early waits for the others; the wavefront pays a latency per line of
 // its longest path, not per step of it.
+//
+// Round 5: the steps themselves. Round 4's loop branched on the kind of step (border / diagonal / probe / either gap,
+// each with its own copy of the 16-byte flush): with 64 lanes on 64 different paths the wavefront ran EVERY arm, ~165
+// VALU instructions and ~45 branches per step (profiles/r05_pmc_cfg3full_walk_planes_kernel.json: 7.0e7 instructions
+// per 250k pairs), and at four wavefronts per SIMD that made the walk as much VALU- as latency-bound. Now a step is one
+// straight block under one exec mask: the four flags of the cell come with ONE ds_read_b128 (COLMAJOR lines hold a
+// column's four planes side by side), "off the diagonal: E or F?" is decided in the step that finds it out (no probe
+// step), everything is a select, the operations collect in a 128-bit shift register (four v_alignbit per step) and
+// leave 16 bytes at a time.
+template <bool COLMAJOR>
 __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     // (the query in dynamic LDS, sized by its length: a fixed 4 KB of it cost the CU wavefronts it has registers for)
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
-    __shared__ uint32_t lineLds[16 * 64];   // [plane * 4 + column % 4][lane]: no two lanes share a bank
+    // COLMAJOR: [column % 4][lane] x the four planes; else [plane * 4 + column % 4][lane] dwords (no two lanes share a bank)
+    __shared__ uint4 lineLds[4 * 64];
     __shared__ uint32_t resLds[5 * 64];     // the target residues of sixteen columns (five dwords: any alignment)
     for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];   // (launchWalk: the query fits)
     __syncthreads();
@@ -726,68 +737,60 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     const uint32_t* planeBase = reinterpret_cast<const uint32_t*>(a.dirs + (int64_t)(idx >> 6) * a.dirWaveStride) + lane * 16;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(a.residues);  // hipMalloc'ed: aligned
     const int slot = a.slotByOut ? job.out : idx;
-    uint8_t* ops = a.ops + (int64_t)slot * a.opsSlot;     // (launchWalk: fixed slots of whole 16-byte pieces)
-    int64_t pos = a.opsSlot;
-    // operations leave 16 bytes at a time (a dword per store left every line of the slot written four times over:
-    // 149 MB of HBM writes for 17 MB of operations, profiles/r04a_pmc_cfg3full_walk_planes_kernel.json)
-    uint32_t acc = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;   // the dword being filled; whole dwords, w0 the newest
-    int i = n - 1, j = m - 1, state = 0, len = 0;
-    bool probe = false;       // state 0, off the diagonal: is it E?
-    int64_t have = -1;        // the line in LDS (tile index), -1: none
+    uint8_t* ops = a.ops + (int64_t)slot * a.opsSlot;     // (launchWalk: fixed slots of whole 16-byte pieces, < 2 GB)
+    int pos = (int)a.opsSlot;
+    // the last sixteen operations, the newest in the lowest byte of w0: what ops[pos .. pos + 16) holds or will hold
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    int i = n - 1, j = m - 1, state = 0, len = 0;   // state: 0 = H, 1 = in a gap of the query (E), 2 = of the target (F)
+    int have = -1;            // the line in LDS (tile index), -1: none
     int resHave = -1;         // ... and the block of sixteen columns whose residues are
-    auto emit = [&](uint32_t op) {
-        ++len;
-        --pos;
-        acc = (acc << 8) | op;  // the newest operation has the lowest address
-        if ((pos & 3) == 0) {
-            w3 = w2; w2 = w1; w1 = w0; w0 = acc;
-            if ((pos & 15) == 0) *reinterpret_cast<uint4*>(ops + pos) = make_uint4(w0, w1, w2, w3);
-        }
-    };
-    const int64_t stripTiles = (a.dirStripColumns >> 2) * 2;   // tiles (column block, half) per strip
+    const uint32_t t3 = (uint32_t)(job.tOff & 3);
+    const int qBase = job.qOff;
+    const uint32_t* const lineWords = reinterpret_cast<const uint32_t*>(lineLds);
+    const int stripTiles = (int)((a.dirStripColumns >> 2) * 2);   // tiles (column block, half) per strip (launchWalk: fits)
     for (;;) {
         // ---- step while any lane holds what its next step reads
         for (;;) {
+            const bool inside = i >= 0 && j >= 0;
             const bool walking = live && (i >= 0 || j >= 0);
-            const bool border = walking && (i < 0 || j < 0);
-            const int64_t tile = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
-            const bool can = border || (walking && tile == have && (j >> 4) == resHave);
+            const int tile = (int)__umul24((uint32_t)(max(i, 0) >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
+            const bool can = walking && (!inside || (tile == have && (j >> 4) == resHave));
             if (__builtin_amdgcn_ballot_w64(can) == 0) break;
-            if (can && i < 0) {          // the rest of the target against nothing
-                emit(2);
-                --j;
-            } else if (can && j < 0) {
-                emit(1);
-                --i;
-            } else if (can) {
-                const int plane = state == 0 ? (probe ? 1 : 0) : state + 1;
-                const int dword = a.dirColumnMajor ? (j & 3) * 4 + plane : plane * 4 + (j & 3);
-                const uint32_t bit = (lineLds[dword * 64 + lane] >> (31 - (i & 31))) & 1u;
-                if (state == 0) {
-                    if (probe) {
-                        state = bit ? 1 : 2;
-                        probe = false;
-                    } else if (bit) {
-                        // residue of column j: byte (tOff + j) of the database, out of the five dwords held
-                        const int64_t at = job.tOff + j;
-                        const int64_t first = (job.tOff + (j & ~15)) >> 2;       // dword of the block's first column
-                        const uint32_t w = resLds[(int)((at >> 2) - first) * 64 + lane];
-                        const uint32_t tr = (w >> ((at & 3) * 8)) & 0xffu;
-                        emit(qlds[job.qOff + i] == tr ? 0 : 3);
-                        --i;
-                        --j;
-                    } else {
-                        probe = true;
-                    }
-                } else if (state == 1) {
-                    emit(2);
-                    if (bit) state = 0;
-                    --j;
+            if (can) {
+                const uint32_t ic = (uint32_t)max(i, 0), jc = (uint32_t)max(j, 0);
+                uint32_t f0, f1, f2, f3;
+                if (COLMAJOR) {
+                    const uint4 p = lineLds[(jc & 3) * 64 + lane];
+                    f0 = p.x; f1 = p.y; f2 = p.z; f3 = p.w;
                 } else {
-                    emit(1);
-                    if (bit) state = 0;
-                    --i;
+                    const uint32_t* at = lineWords + lane * 4 + (jc & 3);   // plane P: slot P * 64 + lane, component column % 4
+                    f0 = at[0]; f1 = at[64 * 4]; f2 = at[2 * 64 * 4]; f3 = at[3 * 64 * 4];
                 }
+                const uint32_t sh = 31u - (ic & 31u);
+                const bool fromDiag = (f0 >> sh) & 1u, fromE = (f1 >> sh) & 1u;
+                const bool openedE = (f2 >> sh) & 1u, openedF = (f3 >> sh) & 1u;
+                // residue of column j: byte (tOff + j) of the database, out of the five dwords held
+                const uint32_t rel = ((t3 + jc) >> 2) - ((t3 + (jc & ~15u)) >> 2);
+                const uint32_t tr = (resLds[rel * 64 + lane] >> (((t3 + jc) & 3u) * 8u)) & 0xffu;
+                const uint32_t qr = qlds[qBase + (int)ic];
+                const bool diag = inside && state == 0 && fromDiag;
+                // the gap this step is in: the one it was in, the one the cell says it came from, or - on a border -
+                // the only one left (i < 0: the rest of the target against nothing)
+                int gap = state == 0 ? (fromE ? 1 : 2) : state;
+                gap = inside ? gap : (i < 0 ? 1 : 2);
+                const bool inE = gap == 1;
+                const uint32_t op = diag ? (qr == tr ? 0u : 3u) : (inE ? 2u : 1u);
+                const bool opened = inE ? openedE : openedF;
+                state = (diag || (inside && opened)) ? 0 : gap;
+                i -= (diag || !inE) ? 1 : 0;
+                j -= (diag || inE) ? 1 : 0;
+                ++len;
+                --pos;
+                w3 = __builtin_amdgcn_alignbit(w3, w2, 24);
+                w2 = __builtin_amdgcn_alignbit(w2, w1, 24);
+                w1 = __builtin_amdgcn_alignbit(w1, w0, 24);
+                w0 = (w0 << 8) | op;
+                if ((pos & 15) == 0) *reinterpret_cast<uint4*>(ops + pos) = make_uint4(w0, w1, w2, w3);
             }
         }
         // ---- one round trip: every unfinished lane fetches the line of its current cell (and, every fourth
@@ -795,12 +798,12 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
         const bool walking = live && i >= 0 && j >= 0;
         if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
         if (walking) {
-            const int64_t tile = (int64_t)(i >> 6) * stripTiles + (int64_t)(j >> 2) * 2 + ((i >> 5) & 1);
+            const int tile = (int)__umul24((uint32_t)(i >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
             const bool newLine = tile != have, newRes = (j >> 4) != resHave;
             uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
             if (newLine) {
-                const uint4* src = reinterpret_cast<const uint4*>(planeBase + tile * (kLanes * 16));
+                const uint4* src = reinterpret_cast<const uint4*>(planeBase + (int64_t)tile * (kLanes * 16));
                 p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];
             }
             if (newRes) {
@@ -809,10 +812,8 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
             }
             if (newLine) {
                 have = tile;
-                lineLds[0 * 64 + lane] = p0.x; lineLds[1 * 64 + lane] = p0.y; lineLds[2 * 64 + lane] = p0.z; lineLds[3 * 64 + lane] = p0.w;
-                lineLds[4 * 64 + lane] = p1.x; lineLds[5 * 64 + lane] = p1.y; lineLds[6 * 64 + lane] = p1.z; lineLds[7 * 64 + lane] = p1.w;
-                lineLds[8 * 64 + lane] = p2.x; lineLds[9 * 64 + lane] = p2.y; lineLds[10 * 64 + lane] = p2.z; lineLds[11 * 64 + lane] = p2.w;
-                lineLds[12 * 64 + lane] = p3.x; lineLds[13 * 64 + lane] = p3.y; lineLds[14 * 64 + lane] = p3.z; lineLds[15 * 64 + lane] = p3.w;
+                // (either order of the line's sixteen dwords: four of them side by side per slot)
+                lineLds[0 * 64 + lane] = p0; lineLds[1 * 64 + lane] = p1; lineLds[2 * 64 + lane] = p2; lineLds[3 * 64 + lane] = p3;
             }
             if (newRes) {
                 resHave = j >> 4;
@@ -822,18 +823,12 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
         }
     }
     if (live) {
-        // what has not left yet: the partly filled dword's top bytes, then the whole dwords up to the next
-        // 16-byte boundary
-        int64_t at = pos;
-        if (at & 3) {
-            const int fill = 4 - (int)(at & 3);
-            for (int x = 0; x < fill; ++x) ops[at + x] = (uint8_t)(acc >> (8 * x));
-            at += fill;
+        // what has not left yet: the operations from pos up to the next 16-byte boundary, the lowest bytes of the register
+        const int rest = (16 - (pos & 15)) & 15;
+        for (int x = 0; x < rest; ++x) {
+            const uint32_t w = x < 4 ? w0 : x < 8 ? w1 : x < 12 ? w2 : w3;
+            ops[pos + x] = (uint8_t)(w >> (8 * (x & 3)));
         }
-        const int whole = (int)(((16 - (at & 15)) & 15) >> 2);
-        if (whole > 0) *reinterpret_cast<uint32_t*>(ops + at) = w0;
-        if (whole > 1) *reinterpret_cast<uint32_t*>(ops + at + 4) = w1;
-        if (whole > 2) *reinterpret_cast<uint32_t*>(ops + at + 8) = w2;
         a.opsLen[slot] = len;
     }
 }
@@ -1236,7 +1231,14 @@ hipError_t launchWalk(const WalkArgs& a, hipStream_t stream) {
         // (what the query-profile form of the direction pass guarantees: host_full.inc)
         if (a.dirWaveStride <= 0 || (a.dirStripColumns & 3) || a.opsOff || (a.opsSlot & 15) || a.queryLength > kWalkQueryLds)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(walk_planes_kernel, dim3((a.nJobs + 63) / 64), dim3(64), (size_t)((a.queryLength + 15) & ~15), stream, a);
+        // (tiles and slot offsets as 32-bit numbers in the kernel)
+        if (a.opsSlot >= (1ll << 31) || (a.dirStripColumns >> 1) * ((a.queryLength + 63) / 64 + 1) >= (1ll << 31) ||
+            (a.dirStripColumns >> 1) >= (1 << 24))
+            return hipErrorInvalidValue;
+        const dim3 grid((a.nJobs + 63) / 64), block(64);
+        const size_t lds = (size_t)((a.queryLength + 15) & ~15);
+        if (a.dirColumnMajor) hipLaunchKernelGGL(walk_planes_kernel<true>, grid, block, lds, stream, a);
+        else hipLaunchKernelGGL(walk_planes_kernel<false>, grid, block, lds, stream, a);
         if (!a.headWaves) return hipGetLastError();
     }
     hipLaunchKernelGGL(walk_kernel, dim3((a.nJobs + 63) / 64), dim3(64), 0, stream, a);
