@@ -109,7 +109,9 @@ static __device__ __forceinline__ void foldPlanes(const uint32_t acc[4], uint32_
     outB = __builtin_amdgcn_perm(t01, t23, 0x07060302u);
 }
 
-template <bool BIASED, int kPkWaves>
+// MULTI: queries of several strips (the last row of a strip travels to the next through a.boundary); a one-strip
+// query's kernel holds neither those rows nor the registers they are fetched into two columns ahead.
+template <bool BIASED, int kPkWaves, bool MULTI>
 __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_kernel(PerPairArgs a) {
     constexpr int kPkBlock = kPkWaves * kLanes;
     extern __shared__ __attribute__((aligned(16))) uint8_t pkLds[];
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
     }
     maxQ = __builtin_amdgcn_readfirstlane(maxQ);
     maxL = __builtin_amdgcn_readfirstlane(maxL);
-    const int nStrips = (maxQ + kLanes - 1) / kLanes;
+    const int nStrips = MULTI ? (maxQ + kLanes - 1) / kLanes : 1;   // (launchPerPairPackedTrace: one strip unless MULTI)
 
     const uint32_t c2 = both(c), kc2 = kPkC + both(c - 1);
     const uint32_t negBias2 = 0u - both(a.packedBias);
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
     ResidueStream rsA{a.residues + jobA.tOff, a.residues, a.residues + a.residueCount - 4, (uint32_t)A * 0x01010101u, LA};
     ResidueStream rsB{a.residues + jobB.tOff, a.residues, a.residues + a.residueCount - 4, (uint32_t)A * 0x01010101u, LB};
     // strip boundaries of the wavefront: (stored H, F before it met that H) of the strip's last row, per column
-    uint2* bnd = a.boundary ? reinterpret_cast<uint2*>(a.boundary) + (int64_t)W * a.boundaryStride * kLanes + lane : nullptr;
+    uint2* bnd = MULTI && a.boundary ? reinterpret_cast<uint2*>(a.boundary) + (int64_t)W * a.boundaryStride * kLanes + lane : nullptr;
     // lines of the two pairs: [pair / 64][strip][column / 4][rows 0-31 | 32-63][pair % 64][column % 4][plane]
     uint8_t* const waveDirsA = a.dirs + (int64_t)(W * 2) * a.dirWaveStride;        // (wave-uniform: the lines of pair 0 of either half)
     uint8_t* const waveDirsB = a.dirs + (int64_t)(W * 2 + 1) * a.dirWaveStride;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
         // cost the kernel a hundred spilled registers.
         auto sweepStrip = [&](auto groupsTag) {
             constexpr int GROUPS = decltype(groupsTag)::value, ROWS = GROUPS * 8;
-            const bool toNext = s + 1 < nStrips;
+            const bool toNext = MULTI && s + 1 < nStrips;
             // the halves' first rows along the profile; rows beyond the query read the pad bytes behind it
             const int ysA = min(jobA.qOff + row0, Qtot), ysB = min(jobB.qOff + row0, Qtot);
             const uint32_t shiftA = (uint32_t)ysA & 3u, shiftB = (uint32_t)ysB & 3u;
@@ -214,8 +216,12 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
             // the first profile dwords of column j + 1 can be fetched while column j is computed
             uint32_t wcurA = rsA.inPlace(rsA.fetchRaw(0), 0), rawNextA = rsA.fetchRaw(4);
             uint32_t wcurB = rsB.inPlace(rsB.fetchRaw(0), 0), rawNextB = rsB.fetchRaw(4);
-            uint2 aboveNext = make_uint2(top2, top2);
-            if (s > 0) aboveNext = bnd[0];
+            uint2 aboveNext = make_uint2(top2, top2), aboveNext2 = aboveNext;
+            // (two columns ahead: one ahead the direction kernel of Q = 300 took 7.06 ms per launch, two 6.56)
+            if (MULTI && s > 0) {
+                aboveNext = bnd[0];
+                aboveNext2 = bnd[(int64_t)min(1, maxL - 1) * kLanes];
+            }
             const int sweep = (maxL + 3) & ~3;
             // "E was opened" of column j is known when column j - 1 is done: the planes of the column before wait
             // here (column 0 opens from the border)
@@ -245,9 +251,10 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
                 const uint32_t* const prowNextA = rowOf(tnA, yAlA);
                 const uint32_t* const prowNextB = rowOf(tnB, yAlB);
                 uint32_t hsUp = top2, fOldUp = top2;
-                if (s > 0) {
+                if (MULTI && s > 0) {
                     const uint2 above = aboveNext;
-                    aboveNext = bnd[(int64_t)min(j + 1, maxL - 1) * kLanes];   // (unconditional: no copy behind the load)
+                    aboveNext = aboveNext2;
+                    aboveNext2 = bnd[(int64_t)min(j + 2, maxL - 1) * kLanes];   // (unconditional: no copy behind the load)
                     hsUp = above.x;
                     fOldUp = above.y;
                 }
@@ -773,11 +780,11 @@ static inline bool firstUseHere(uint64_t* seen) {
     return !(old & bit);
 }
 
-template <bool BIASED, int WAVES>
+template <bool BIASED, int WAVES, bool MULTI>
 static hipError_t launchPackedTraceAs(const PerPairArgs& a, size_t ldsBytes, hipStream_t stream) {
     static uint64_t configured = 0;   // one bit per device: the attribute belongs to the device
     if (firstUseHere(&configured)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&perpair_packed_trace_kernel<BIASED, WAVES>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&perpair_packed_trace_kernel<BIASED, WAVES, MULTI>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             int dev = 0;
@@ -787,7 +794,7 @@ static hipError_t launchPackedTraceAs(const PerPairArgs& a, size_t ldsBytes, hip
         }
     }
     const int waves = (a.nJobs + 2 * kLanes - 1) / (2 * kLanes);
-    hipLaunchKernelGGL((perpair_packed_trace_kernel<BIASED, WAVES>), dim3((waves + WAVES - 1) / WAVES), dim3(WAVES * kLanes),
+    hipLaunchKernelGGL((perpair_packed_trace_kernel<BIASED, WAVES, MULTI>), dim3((waves + WAVES - 1) / WAVES), dim3(WAVES * kLanes),
                        ldsBytes, stream, a);
     return hipGetLastError();
 }
@@ -797,10 +804,20 @@ hipError_t launchPerPairPackedTrace(const PerPairArgs& a, size_t ldsBytes, hipSt
     if (a.profileStride <= 0 || a.dirs == nullptr || (a.dirStripColumns & 3)) return hipErrorInvalidValue;
     const size_t profile = (size_t)(a.alphabet + 1) * a.profileStride + 16;
     const bool four = ldsBytes == 4 * (size_t)kPkStageBytes + profile;
-    if (a.packedBias > 0) {
-        return four ? launchPackedTraceAs<true, 4>(a, ldsBytes, stream) : launchPackedTraceAs<true, kPkMaxWaves>(a, ldsBytes, stream);
+    // (host_full.inc: the rows between strips are there exactly when a window has more than 64 rows)
+    const bool multi = a.boundary != nullptr;
+    if (multi && a.boundaryStride <= 0) return hipErrorInvalidValue;
+    const int which = (a.packedBias > 0 ? 4 : 0) + (four ? 2 : 0) + (multi ? 1 : 0);
+    switch (which) {
+        case 7: return launchPackedTraceAs<true, 4, true>(a, ldsBytes, stream);
+        case 6: return launchPackedTraceAs<true, 4, false>(a, ldsBytes, stream);
+        case 5: return launchPackedTraceAs<true, kPkMaxWaves, true>(a, ldsBytes, stream);
+        case 4: return launchPackedTraceAs<true, kPkMaxWaves, false>(a, ldsBytes, stream);
+        case 3: return launchPackedTraceAs<false, 4, true>(a, ldsBytes, stream);
+        case 2: return launchPackedTraceAs<false, 4, false>(a, ldsBytes, stream);
+        case 1: return launchPackedTraceAs<false, kPkMaxWaves, true>(a, ldsBytes, stream);
+        default: return launchPackedTraceAs<false, kPkMaxWaves, false>(a, ldsBytes, stream);
     }
-    return four ? launchPackedTraceAs<false, 4>(a, ldsBytes, stream) : launchPackedTraceAs<false, kPkMaxWaves>(a, ldsBytes, stream);
 }
 
 
