@@ -742,8 +742,11 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     // the last sixteen operations, the newest in the lowest byte of w0: what ops[pos .. pos + 16) holds or will hold
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     int i = n - 1, j = m - 1, state = 0, len = 0;   // state: 0 = H, 1 = in a gap of the query (E), 2 = of the target (F)
-    int have = -1;            // the line in LDS (tile index), -1: none
-    int resHave = -1;         // ... and the block of sixteen columns whose residues are
+    // the line in LDS covers rows iLo .. iLo + 31 of columns jLo .. jLo + 3, the residues columns resLo .. resLo + 15;
+    // a path only moves up and to the left, so "still on the line" is i >= iLo && j >= jLo (and jLo >= resLo: both are
+    // made current in the same round trip)
+    int iLo = INT32_MAX, jLo = INT32_MAX, resLo = INT32_MAX;
+    uint32_t resBase = 0;     // dword of the residue block's first column, counted from the target's first dword
     const uint32_t t3 = (uint32_t)(job.tOff & 3);
     const int qBase = job.qOff;
     const uint32_t* const lineWords = reinterpret_cast<const uint32_t*>(lineLds);
@@ -751,10 +754,9 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     for (;;) {
         // ---- step while any lane holds what its next step reads
         for (;;) {
-            const bool inside = i >= 0 && j >= 0;
+            const bool inside = (i | j) >= 0;
             const bool walking = live && (i >= 0 || j >= 0);
-            const int tile = (int)__umul24((uint32_t)(max(i, 0) >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
-            const bool can = walking && (!inside || (tile == have && (j >> 4) == resHave));
+            const bool can = walking && (!inside || (i >= iLo && j >= jLo));
             if (__builtin_amdgcn_ballot_w64(can) == 0) break;
             if (can) {
                 const uint32_t ic = (uint32_t)max(i, 0), jc = (uint32_t)max(j, 0);
@@ -770,8 +772,8 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                 const bool fromDiag = (f0 >> sh) & 1u, fromE = (f1 >> sh) & 1u;
                 const bool openedE = (f2 >> sh) & 1u, openedF = (f3 >> sh) & 1u;
                 // residue of column j: byte (tOff + j) of the database, out of the five dwords held
-                const uint32_t rel = ((t3 + jc) >> 2) - ((t3 + (jc & ~15u)) >> 2);
-                const uint32_t tr = (resLds[rel * 64 + lane] >> (((t3 + jc) & 3u) * 8u)) & 0xffu;
+                const uint32_t rel = ((t3 + jc) >> 2) - resBase;
+                const uint32_t tr = (resLds[(inside ? rel : 0u) * 64 + lane] >> (((t3 + jc) & 3u) * 8u)) & 0xffu;
                 const uint32_t qr = qlds[qBase + (int)ic];
                 const bool diag = inside && state == 0 && fromDiag;
                 // the gap this step is in: the one it was in, the one the cell says it came from, or - on a border -
@@ -798,11 +800,11 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
         const bool walking = live && i >= 0 && j >= 0;
         if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
         if (walking) {
-            const int tile = (int)__umul24((uint32_t)(i >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
-            const bool newLine = tile != have, newRes = (j >> 4) != resHave;
+            const bool newLine = !(i >= iLo && j >= jLo), newRes = j < resLo;
             uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
             if (newLine) {
+                const int tile = (int)__umul24((uint32_t)(i >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
                 const uint4* src = reinterpret_cast<const uint4*>(planeBase + (int64_t)tile * (kLanes * 16));
                 p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];
             }
@@ -811,12 +813,14 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                 r0 = words[first]; r1 = words[first + 1]; r2 = words[first + 2]; r3 = words[first + 3]; r4 = words[first + 4];
             }
             if (newLine) {
-                have = tile;
+                iLo = i & ~31;
+                jLo = j & ~3;
                 // (either order of the line's sixteen dwords: four of them side by side per slot)
                 lineLds[0 * 64 + lane] = p0; lineLds[1 * 64 + lane] = p1; lineLds[2 * 64 + lane] = p2; lineLds[3 * 64 + lane] = p3;
             }
             if (newRes) {
-                resHave = j >> 4;
+                resLo = j & ~15;
+                resBase = (t3 + (uint32_t)resLo) >> 2;
                 resLds[0 * 64 + lane] = r0; resLds[1 * 64 + lane] = r1; resLds[2 * 64 + lane] = r2;
                 resLds[3 * 64 + lane] = r3; resLds[4 * 64 + lane] = r4;
             }
