@@ -722,8 +722,9 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     // (the query in dynamic LDS, sized by its length: a fixed 4 KB of it cost the CU wavefronts it has registers for)
     extern __shared__ __attribute__((aligned(16))) uint8_t qlds[];
     // COLMAJOR: [column % 4][lane] x the four planes; else [plane * 4 + column % 4][lane] dwords (no two lanes share a bank)
-    __shared__ uint4 lineLds[4 * 64];
-    __shared__ uint32_t resLds[5 * 64];     // the target residues of sixteen columns (five dwords: any alignment)
+    // TWO lines per lane: the one the path is on and its left neighbour (the next one of a path that keeps to its half
+    // strip) - a wavefront pays a round trip per line of its longest path, and with the steps cheap that latency is the walk
+    __shared__ uint4 lineLds[8 * 64];
     for (int x = threadIdx.x; x < a.queryLength; x += 64) qlds[x] = a.query[x];   // (launchWalk: the query fits)
     __syncthreads();
     const int lane = threadIdx.x;
@@ -742,11 +743,11 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
     // the last sixteen operations, the newest in the lowest byte of w0: what ops[pos .. pos + 16) holds or will hold
     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
     int i = n - 1, j = m - 1, state = 0, len = 0;   // state: 0 = H, 1 = in a gap of the query (E), 2 = of the target (F)
-    // the line in LDS covers rows iLo .. iLo + 31 of columns jLo .. jLo + 3, the residues columns resLo .. resLo + 15;
-    // a path only moves up and to the left, so "still on the line" is i >= iLo && j >= jLo (and jLo >= resLo: both are
-    // made current in the same round trip)
-    int iLo = INT32_MAX, jLo = INT32_MAX, resLo = INT32_MAX;
+    // the lines in LDS cover rows iLo .. iLo + 31 of columns jBase .. jBase + 7, the residues columns resLo .. resLo + 15
+    // (resLo <= max(jBase, 0)); a path only moves up and to the left, so "still on the lines" is i >= iLo && j >= jBase
+    int iLo = INT32_MAX, jBase = INT32_MAX, resLo = INT32_MAX;   // (jBase: column of slot 0, four below the line's own)
     uint32_t resBase = 0;     // dword of the residue block's first column, counted from the target's first dword
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;   // the target residues of sixteen columns (five dwords: any alignment)
     const uint32_t t3 = (uint32_t)(job.tOff & 3);
     const int qBase = job.qOff;
     const uint32_t* const lineWords = reinterpret_cast<const uint32_t*>(lineLds);
@@ -756,16 +757,18 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
         for (;;) {
             const bool inside = (i | j) >= 0;
             const bool walking = live && (i >= 0 || j >= 0);
-            const bool can = walking && (!inside || (i >= iLo && j >= jLo));
+            const bool can = walking && (!inside || (i >= iLo && j >= jBase));
             if (__builtin_amdgcn_ballot_w64(can) == 0) break;
             if (can) {
                 const uint32_t ic = (uint32_t)max(i, 0), jc = (uint32_t)max(j, 0);
                 uint32_t f0, f1, f2, f3;
+                const uint32_t slot = (uint32_t)((int)jc - jBase) & 7u;
                 if (COLMAJOR) {
-                    const uint4 p = lineLds[(jc & 3) * 64 + lane];
+                    const uint4 p = lineLds[slot * 64 + lane];
                     f0 = p.x; f1 = p.y; f2 = p.z; f3 = p.w;
                 } else {
-                    const uint32_t* at = lineWords + lane * 4 + (jc & 3);   // plane P: slot P * 64 + lane, component column % 4
+                    // plane P of line L (0: the left one): slot L * 4 + P, component column % 4
+                    const uint32_t* at = lineWords + ((slot & 4u) * 64 + lane) * 4 + (slot & 3u);
                     f0 = at[0]; f1 = at[64 * 4]; f2 = at[2 * 64 * 4]; f3 = at[3 * 64 * 4];
                 }
                 const uint32_t sh = 31u - (ic & 31u);
@@ -773,7 +776,8 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
                 const bool openedE = (f2 >> sh) & 1u, openedF = (f3 >> sh) & 1u;
                 // residue of column j: byte (tOff + j) of the database, out of the five dwords held
                 const uint32_t rel = ((t3 + jc) >> 2) - resBase;
-                const uint32_t tr = (resLds[(inside ? rel : 0u) * 64 + lane] >> (((t3 + jc) & 3u) * 8u)) & 0xffu;
+                const uint32_t rw = rel == 0 ? r0 : rel == 1 ? r1 : rel == 2 ? r2 : rel == 3 ? r3 : r4;
+                const uint32_t tr = (rw >> (((t3 + jc) & 3u) * 8u)) & 0xffu;
                 const uint32_t qr = qlds[qBase + (int)ic];
                 const bool diag = inside && state == 0 && fromDiag;
                 // the gap this step is in: the one it was in, the one the cell says it came from, or - on a border -
@@ -800,29 +804,32 @@ __global__ __launch_bounds__(64) void walk_planes_kernel(WalkArgs a) {
         const bool walking = live && i >= 0 && j >= 0;
         if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
         if (walking) {
-            const bool newLine = !(i >= iLo && j >= jLo), newRes = j < resLo;
-            uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
-            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+            // (every walking lane is off its lines here. The residues held always reach down to the lines' first column:
+            // sixteen columns that end with the line's own four)
+            const bool newLine = true, newRes = max((j & ~3) - 4, 0) < resLo;
+            uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0, l0 = p0, l1 = p0, l2 = p0, l3 = p0;
             if (newLine) {
                 const int tile = (int)__umul24((uint32_t)(i >> 6), (uint32_t)stripTiles) + (j >> 2) * 2 + ((i >> 5) & 1);
                 const uint4* src = reinterpret_cast<const uint4*>(planeBase + (int64_t)tile * (kLanes * 16));
                 p0 = src[0]; p1 = src[1]; p2 = src[2]; p3 = src[3];
+                if (j >= 4) {
+                    // the same rows of the four columns to the left: two tiles back (tiles alternate between the halves)
+                    const uint4* left = src - 2 * (kLanes * 4);
+                    l0 = left[0]; l1 = left[1]; l2 = left[2]; l3 = left[3];
+                }
             }
             if (newRes) {
-                const int64_t first = (job.tOff + (j & ~15)) >> 2;
+                resLo = max((j & ~3) - 12, 0);
+                const int64_t first = (job.tOff + resLo) >> 2;
                 r0 = words[first]; r1 = words[first + 1]; r2 = words[first + 2]; r3 = words[first + 3]; r4 = words[first + 4];
+                resBase = (t3 + (uint32_t)resLo) >> 2;
             }
             if (newLine) {
                 iLo = i & ~31;
-                jLo = j & ~3;
-                // (either order of the line's sixteen dwords: four of them side by side per slot)
-                lineLds[0 * 64 + lane] = p0; lineLds[1 * 64 + lane] = p1; lineLds[2 * 64 + lane] = p2; lineLds[3 * 64 + lane] = p3;
-            }
-            if (newRes) {
-                resLo = j & ~15;
-                resBase = (t3 + (uint32_t)resLo) >> 2;
-                resLds[0 * 64 + lane] = r0; resLds[1 * 64 + lane] = r1; resLds[2 * 64 + lane] = r2;
-                resLds[3 * 64 + lane] = r3; resLds[4 * 64 + lane] = r4;
+                jBase = (j & ~3) - 4;
+                // (either order of a line's sixteen dwords: four of them side by side per slot)
+                lineLds[0 * 64 + lane] = l0; lineLds[1 * 64 + lane] = l1; lineLds[2 * 64 + lane] = l2; lineLds[3 * 64 + lane] = l3;
+                lineLds[4 * 64 + lane] = p0; lineLds[5 * 64 + lane] = p1; lineLds[6 * 64 + lane] = p2; lineLds[7 * 64 + lane] = p3;
             }
         }
     }
