@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64) void walk_kernel(WalkArgs a) {
 //
 // Round 5: the steps themselves. Round 4's loop branched on the kind of step (border / diagonal / probe / either gap,
 // each with its own copy of the 16-byte flush): with 64 lanes on 64 different paths the wavefront ran EVERY arm, ~165
-// VALU instructions and ~45 branches per step (profiles/r05_pmc_cfg3full_walk_planes_kernel.json: 7.0e7 instructions
+// VALU instructions and ~45 branches per step (profiles/r05a_pmc_cfg3full_walk_planes_kernel.json: 7.0e7 instructions
 // per 250k pairs), and at four wavefronts per SIMD that made the walk as much VALU- as latency-bound. Now a step is one
 // straight block under one exec mask: the four flags of the cell come with ONE ds_read_b128 (COLMAJOR lines hold a
 // column's four planes side by side), "off the diagonal: E or F?" is decided in the step that finds it out (no probe

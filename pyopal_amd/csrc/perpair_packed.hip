@@ -416,12 +416,13 @@ __global__ __launch_bounds__(kPkWaves * kLanes, 2) void perpair_packed_trace_ker
 
 // ---- the start-cell scan with two pairs per lane -------------------------------------------------------
 // The reversed-prefix scans (perpair.hip: perpair_scan_refill_kernel, perpair_profile_kernel<kAllCells>) on the
-// same halves. Persistent wavefronts; every HALF of a lane runs its own schedule: its own pair, its own strip of
-// 64 query rows, its own column - a half that is done with a strip goes on to the pair's next strip, a half that
-// is done with its pair takes the next pair of the list (one atomic per wavefront and refill), at multiples of
-// four columns so that the four-residue loads stay in step. Between strips the last row travels through a
-// private line of HBM per half, 4 bytes per column, read back one column ahead; strip 0 "reads" a constant
-// line that holds the border.
+// same halves, for queries of ONE strip (several: perpair_packed_strips.inc, the lanes in step). Persistent
+// wavefronts; every HALF of a lane runs its own schedule: its own pair, its own column - a half that is done with
+// its pair takes the next pair of the list (one atomic per wavefront and refill), at multiples of four columns so
+// that the four-residue loads stay in step. What this costs: 1M pairs on 3072 x 128 half-slots are 2.5 pairs per
+// slot, and when the list runs out every wavefront finishes its own stragglers - the halves are busy 70 % of a
+// wavefront's life (tools/r05_scan_schedule_sim.py; no order known beforehand helps: the window's length is what
+// the scan finds out).
 //
 // Cells on the column scale X' = X + j ext, everything times 8: the three low bits of a value are free and the
 // column's maximum is folded over KEYS, value + 7 - (group of eight rows), so that the maximum itself says which
