@@ -196,6 +196,7 @@ struct PerPairArgs {
     const int32_t* fwdEndQ;
     const int32_t* fwdEndT;
     const int64_t* fwdOffsets;
+    const int* order;         // ... taken in this order (null: 0, 1, 2, ...): the persistent scan, longest prefixes first
 };
 hipError_t launchPerPair(const PerPairArgs& a, int mode, hipStream_t stream);
 // perpair_packed.hip: the direction pass with two pairs per lane. packedTraceFits says whether it applies (rows /
@@ -333,6 +334,8 @@ hipError_t launchTraceJobs(int n, int rules, const int32_t* startQ, const int32_
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
                                   hipStream_t stream, int* headWaves = nullptr, int maxHeadWaves = 0,
                                   int queryRows = 0);
+// order[] = the indices 0 .. n - 1 by keys[] descending (negative keys count as 0); bins: 8192 ints
+hipError_t launchSortIndicesByKey(const int32_t* keys, int n, int maxValue, int* bins, int* order, hipStream_t stream);
 // blockSums: (n + 255) / 256 entries of scratch; *base = bytes already in `out`, *next = *base + this batch
 hipError_t launchGatherOps(int n, const uint8_t* slots, int64_t slotBytes, const int32_t* lens,
                            int64_t* blockSums, const int64_t* base, int64_t* next, uint8_t* out,

@@ -1138,6 +1138,58 @@ __global__ __launch_bounds__(kSortBlock) void job_length_scatter_kernel(const Pa
     }
 }
 
+// ---- the same sort for bare indices (round 5): order[] = 0 .. n - 1 by keys[] descending ---------------------
+// The persistent start-cell scan takes its pairs in this order, longest PREFIXES first: what it cannot know is how far
+// a scan runs, but it never runs beyond its prefix - with the short prefixes last, the stragglers every wavefront
+// finishes alone when the list has run out are short ones (simulated on cfg3's own windows: the last wavefront done at
+// column 212 instead of 264, tools/r05_scan_schedule_sim.py).
+__global__ __launch_bounds__(kSortBlock) void key_histogram_kernel(const int32_t* keys, int n, int maxKey, int shift, int* bins) {
+    extern __shared__ int local[];
+    for (int b = threadIdx.x; b <= maxKey; b += kSortBlock) local[b] = 0;
+    __syncthreads();
+    for (int k = blockIdx.x * kSortBlock + threadIdx.x; k < n; k += gridDim.x * kSortBlock)
+        atomicAdd(&local[min(max(keys[k], 0) >> shift, maxKey)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b <= maxKey; b += kSortBlock)
+        if (local[b]) atomicAdd(&bins[b], local[b]);
+}
+
+__global__ __launch_bounds__(kSortBlock) void key_scatter_kernel(const int32_t* keys, int n, int maxKey, int shift, int* bins,
+                                                                 int* order) {
+    extern __shared__ int local[];
+    for (int b = threadIdx.x; b <= maxKey; b += kSortBlock) local[b] = 0;
+    __syncthreads();
+    const int64_t k = (int64_t)blockIdx.x * kSortBlock + threadIdx.x;
+    int key = 0, rank = 0;
+    if (k < n) {
+        key = min(max(keys[k], 0) >> shift, maxKey);
+        rank = atomicAdd(&local[key], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b <= maxKey; b += kSortBlock) {
+        const int c = local[b];
+        if (c) local[b] = atomicAdd(&bins[b], c);
+    }
+    __syncthreads();
+    if (k < n) order[local[key] + rank] = (int)k;
+}
+
+hipError_t launchSortIndicesByKey(const int32_t* keys, int n, int maxValue, int* bins, int* order, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    SortKey sk{0, 1, 0};
+    while ((maxValue >> sk.shift) >= kSortMaxBins) ++sk.shift;
+    const int maxKey = std::max(maxValue, 0) >> sk.shift;
+    hipError_t e = hipMemsetAsync(bins, 0, (size_t)(maxKey + 1) * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int blocks = std::min((n + kSortBlock - 1) / kSortBlock, 1024);
+    hipLaunchKernelGGL(key_histogram_kernel, dim3(blocks), dim3(kSortBlock), (size_t)(maxKey + 1) * sizeof(int), stream, keys, n,
+                       maxKey, sk.shift, bins);
+    hipLaunchKernelGGL(job_length_offsets_kernel, dim3(1), dim3(kSortBlock), 0, stream, maxKey, bins, n, sk, (int*)nullptr, 0);
+    hipLaunchKernelGGL(key_scatter_kernel, dim3((n + kSortBlock - 1) / kSortBlock), dim3(kSortBlock),
+                       (size_t)(maxKey + 1) * sizeof(int), stream, keys, n, maxKey, sk.shift, bins, order);
+    return hipGetLastError();
+}
+
 hipError_t launchSortJobsByLength(const PairJob* jobs, int n, int maxLen, int* bins, PairJob* sorted,
                                   hipStream_t stream, int* headWaves, int maxHeadWaves, int queryRows) {
     if (n <= 0) return hipSuccess;

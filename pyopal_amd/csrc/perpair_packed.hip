@@ -534,11 +534,12 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                             job = a.jobs[k];
                         } else {
                             // the reversed prefixes anchored on the end cell, straight from the end pass's arrays
-                            const int qe = a.fwdEndQ[k], te = a.fwdEndT[k];
-                            job.out = k;
-                            job.stop = a.fwdScore[k];
+                            const int src = a.order ? a.order[k] : k;
+                            const int qe = a.fwdEndQ[src], te = a.fwdEndT[src];
+                            job.out = src;
+                            job.stop = a.fwdScore[src];
                             if (qe >= 0 && te >= 0) {
-                                job.tOff = a.fwdOffsets[k] + te;
+                                job.tOff = a.fwdOffsets[src] + te;
                                 job.tLen = te + 1;
                                 job.qOff = qe;
                                 job.qLen = qe + 1;

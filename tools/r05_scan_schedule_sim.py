@@ -57,6 +57,8 @@ total = cols.sum()
 print(f"Q={Q} N={N} {GO}/{GE}: {total:.3e} columns, balanced share {total / (3072 * 128):.1f} columns per half")
 for name, order in (("database order (the build)", np.arange(N)),
                     ("by score, highest first", np.argsort(-score, kind="stable")),
+                    ("by the end cell's column, longest prefixes first", np.argsort(-r["end_t"].astype(np.int64), kind="stable")),
+                    ("by the end cell's column in steps of 32, longest first", np.argsort(-(r["end_t"].astype(np.int64) >> 5), kind="stable")),
                     ("by the end cell's row, last rows first", np.argsort(-r["end_q"].astype(np.int64), kind="stable")),
                     ("by min(end row, end column)", np.argsort(-np.minimum(r["end_q"], r["end_t"]).astype(np.int64), kind="stable")),
                     ("by window length, longest first (not known beforehand)", np.argsort(-cols, kind="stable"))):
