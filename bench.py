@@ -512,7 +512,7 @@ def full_pipeline_roofline(res, Q, N, L, wall_ms, alg_bytes_whole):
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
             "note": "kernel_ms / achieved of this block: wall time of the whole call (host-visible results); per kernel below. "
                     "The direction and scan passes are VALU-issue-bound (two pairs per lane on 16-bit halves: 8 / 4.5 instructions "
-                    "per cell), the walk by memory latency (one round trip per 64-byte line of direction bits and wavefront)",
+                    "per cell in the row loops), the walk by memory latency (one round trip per two 64-byte lines of direction bits and wavefront)",
             "kernels": kernels}
 
 
