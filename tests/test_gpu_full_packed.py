@@ -223,3 +223,41 @@ def test_values_beyond_the_half_floats_leave_the_form(capi, lane_per_pair):
     got, routing = search(capi, q, res, off, B62, 11, 1)
     assert routing & PACKED_SCAN == 0, routing
     compare(got, _oracle.search(q, res, off, B62, 11, 1, "full", "sw"), "full", "near-identical copies")
+
+
+def test_orders_and_overlaps_of_the_pipeline_do_not_change_results(capi, tuning):
+    """Round 5's scheduling choices - the scan's pairs longest prefixes first (an index sort: intraseq.hip
+    launchSortIndicesByKey), the windows' rows as a minor key of the direction jobs' sort, the next group's job lists
+    built on the side stream, the host's shares on helper threads - are orders and overlaps, never answers: each
+    switched off alone gives the arrays of the default, and a sample of them equals the checker's."""
+    rng = np.random.default_rng(77)
+    n = 270_000   # (four traceback batches; the scan's order needs four pairs per lane of the chip: 65 536)
+    q = _data.encode(_data.README_QUERY)
+    lengths = np.clip(rng.lognormal(mean=3.6, sigma=0.5, size=n), 5, 400).astype(np.int64)
+    res, off = _data.random_db(rng, lengths)
+    tuning.setenv("MIOPAL_NO_SMALL_SEARCH", "1")
+    db = capi.DeviceDatabase(res, off, 24)
+    try:
+        base = db.search(q, B62, 3, 1, "full", "sw")
+        routing = capi.DeviceDatabase.last_full_routing()
+        assert routing & PACKED_TRACE and routing & PACKED_SCAN and routing & ONE_LAUNCH, routing
+        base = {k: np.array(base[k], copy=True) for k in KEYS}
+        for switch in ("MIOPAL_NO_SCAN_ORDER", "MIOPAL_NO_SORT_BY_ROWS", "MIOPAL_NO_JOBS_AHEAD", "MIOPAL_NO_ASYNC_SHARES"):
+            tuning.setenv(switch, "1")
+            got = db.search(q, B62, 3, 1, "full", "sw")
+            tuning.delenv(switch)
+            for k in KEYS:
+                assert np.array_equal(got[k], base[k]), (switch, k)
+    finally:
+        db.close()
+    sample = np.sort(rng.choice(n, size=300, replace=False))
+    seqs = [res[off[t]:off[t + 1]] for t in sample]
+    sub_off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    sub_off[1:] = np.cumsum([len(x) for x in seqs])
+    want = _oracle.search(q, np.concatenate(seqs), sub_off, B62, 3, 1, "full", "sw")
+    for rank, t in enumerate(sample):
+        assert base["score"][t] == want["score"][rank]
+        assert (base["end_q"][t], base["end_t"][t]) == (want["end_q"][rank], want["end_t"][rank])
+        assert (base["start_q"][t], base["start_t"][t]) == (want["start_q"][rank], want["start_t"][rank])
+        a0, a1 = base["aln_off"][t], base["aln_off"][t + 1]
+        assert np.array_equal(base["aln_flat"][a0:a1], want["aln"][rank]), t
