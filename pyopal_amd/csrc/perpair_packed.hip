@@ -483,6 +483,8 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) HS[i] = E[i] = top2;
     bool exhausted = false;   // wave-uniform: no pair left to take
+    const bool lastRowOnly = a.scanLastRow != 0;              // (wave-uniform)
+    const int lastRowLocal = lastRowOnly ? Qtot - 1 : 0;      // one strip: the query's last row (every HW prefix has them all)
 
     auto fetchRaw = [&](const ScanHalf& h, int j0) -> uint32_t {
         const uint8_t* at = h.tptr - j0 - 3;
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
         aboveHsPrev = hsUp;
         uint32_t gm[GROUPS];
         uint32_t held = 0;
+        uint32_t hLast = 0;   // (scanLastRow: the cell of the query's last row - in the strip's last group of eight)
         uint32_t wloA = prowA[0], wloB = prowB[0], n1A = prowA[1], n1B = prowB[1], fourA = 0, fourB = 0;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
@@ -649,6 +652,7 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
             const uint32_t e = pkMax(E[i], HS[i]);
             const uint32_t f = pkMax(F, hsUp) - ext2;
             const uint32_t h = pkMax3(d, e, f);
+            if (i >= ROWS - 8) hLast = i == lastRowLocal ? h : hLast;   // (wave-uniform)
             // the group's maximum, two rows a step
             const int r = i & 7, g = i >> 3;
             if (r == 1) gm[g] = pkMax(held, h);
@@ -669,13 +673,14 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
             if (g + 1 < GROUPS) cmk = pkMax3(cmk, gm[g] + both(7 - g), gm[g + 1] + both(6 - g));
             else cmk = pkMax(cmk, gm[g] + both(7 - g));
         }
-        const uint32_t x = (cmk & 0xfff8fff8u) ^ tgt2;
+        // (HW, scanLastRow: only the cell of the query's last row answers, and cells above it may well be larger)
+        const uint32_t x = lastRowOnly ? hLast ^ tgt2 : (cmk & 0xfff8fff8u) ^ tgt2;
         const bool hitA = busyA && (x & 0xffffu) == 0, hitB = busyB && (x >> 16) == 0;
         if (__builtin_amdgcn_ballot_w64(hitA || hitB) != 0) {
             const int gstarA = 7 - (int)(cmk & 7u), gstarB = 7 - (int)((cmk >> 16) & 7u);
-            int rowA = 0, rowB = 0;
+            int rowA = lastRowLocal, rowB = lastRowLocal;
 #pragma unroll
-            for (int g = 0; g < GROUPS; ++g) {
+            for (int g = 0; g < GROUPS && !lastRowOnly; ++g) {
                 const bool inA = hitA && gstarA == g, inB = hitB && gstarB == g;
                 if (__builtin_amdgcn_ballot_w64(inA || inB) == 0) continue;
                 // the first row of the group that holds the group's maximum: keys again, value + 7 - row
@@ -706,8 +711,11 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                     // the start cell (what start_cells_kernel makes of the reverse pass: intraseq.hip); a scan that never
                     // met the optimum of the forward pass is reported, its window is the whole prefix
                     const bool found = h.bcol >= 0;
-                    if (!found) atomicExch(a.startChecks, h.out + 1);
-                    const int sq = found ? h.Q - 1 - h.brow : 0, st = found ? L - 1 - h.bcol : 0;
+                    // (HW: the whole query in one gap before the target's first aligned residue is a border cell of the
+                    // reversed problem, which no scan computes: start_cells_kernel, oracle/opal_oracle.c)
+                    const bool border = !found && lastRowOnly && stop == borderGap(h.Q - 1, open, ext);
+                    if (!found && !border) atomicExch(a.startChecks, h.out + 1);
+                    const int sq = found ? h.Q - 1 - h.brow : 0, st = found ? L - 1 - h.bcol : border ? L : 0;
                     a.startQ[h.out] = sq;
                     a.startT[h.out] = st;
                     windowMax = max(windowMax, L - st);

@@ -22,7 +22,7 @@ namespace miopal {
     X(SCAN_BLOCKS_PER_CU) X(SCAN_REFILL_LANES) X(SHORT_STRIDE) X(SMALL_STEPS) X(SPARE_HANDLE_MB)           \
     X(STRIPS) X(STRIPS_RESERVE) X(TAIL_THROTTLE) X(THIN_SIDE) X(TWO_PASS_ENDS) X(UNITS)                    \
     X(UPLOAD_PIECE_KB) X(UPLOAD_STREAMS) X(UPLOAD_THREADS) X(VERBOSE) X(VIEW_CACHE_MB)                     \
-    X(WINDOWS_WHENEVER_POSSIBLE) X(TEST_REFUSE_PAIR_LAUNCH) X(NO_PACKED_OPS) X(STRIP_TIMING) X(SKIP_SHARES) X(SEARCH_UNDER_UPLOAD) X(NO_WIDE_PAIRS) X(NO_SIDE_COPIES) X(NO_EARLY_HOST_SHARE) X(NO_UNPACK_CREW) X(NO_STREAM_STORES) X(NO_PACKED_TRACE) X(NO_PACKED_SCAN) X(NO_ONE_LAUNCH) X(ONE_LAUNCH_GROUP) X(NO_ASYNC_SHARES) X(NO_LATE_RESULT_COPIES) X(PARKED_WORKSPACE_MB) X(NO_SORT_BY_ROWS) X(NO_JOBS_AHEAD) X(NO_SCAN_ORDER)
+    X(WINDOWS_WHENEVER_POSSIBLE) X(TEST_REFUSE_PAIR_LAUNCH) X(NO_PACKED_OPS) X(STRIP_TIMING) X(SKIP_SHARES) X(SEARCH_UNDER_UPLOAD) X(NO_WIDE_PAIRS) X(NO_SIDE_COPIES) X(NO_EARLY_HOST_SHARE) X(NO_UNPACK_CREW) X(NO_STREAM_STORES) X(NO_PACKED_TRACE) X(NO_PACKED_SCAN) X(NO_ONE_LAUNCH) X(ONE_LAUNCH_GROUP) X(NO_ASYNC_SHARES) X(NO_LATE_RESULT_COPIES) X(PARKED_WORKSPACE_MB) X(NO_SORT_BY_ROWS) X(NO_JOBS_AHEAD) X(NO_SCAN_ORDER) X(NO_PACKED_HW_SCAN)
 
 enum class Tune : int {
 #define X(name) name,

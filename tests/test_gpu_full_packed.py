@@ -83,7 +83,7 @@ def test_every_mode_against_the_checker(capi, lane_per_pair, algo, matrix, go, g
         q = _data.random_protein(rng, qlen)
         got, routing = search(capi, q, res, off, matrix, go, ge, algo)
         assert routing & PACKED_TRACE, (routing, qlen)
-        assert bool(routing & PACKED_SCAN) == (algo == "sw"), (routing, qlen)
+        assert bool(routing & PACKED_SCAN) == (algo in ("sw", "hw")), (routing, qlen)   # (OV keeps the 32-bit scan)
         ref = _oracle.search(q, res, off, matrix, go, ge, "full", algo)
         compare(got, ref, "full", f"{algo} Q={qlen} gaps {go}/{ge}")
 
@@ -261,3 +261,33 @@ def test_orders_and_overlaps_of_the_pipeline_do_not_change_results(capi, tuning)
         assert (base["start_q"][t], base["start_t"][t]) == (want["start_q"][rank], want["start_t"][rank])
         a0, a1 = base["aln_off"][t], base["aln_off"][t + 1]
         assert np.array_equal(base["aln_flat"][a0:a1], want["aln"][rank]), t
+
+
+@pytest.mark.parametrize("qlen", [53, 150])
+def test_hw_start_cells_on_the_packed_scan(capi, lane_per_pair, tuning, qlen):
+    """HW: the reversed-prefix scan answers only in the query's last row (perpair_packed.hip, scanLastRow), cells above it
+    may exceed the optimum (targets of tryptophans against a query without one: every real cell is worse than the query
+    in one gap; the case where THAT is the optimum at a real end cell - a border cell of the reversed problem, which no
+    scan computes - is the property tier's). Against the checker, and against the 32-bit scan array by array."""
+    rng = np.random.default_rng(5 + qlen)
+    q = _data.random_protein(rng, qlen)
+    w = int(_data.encode("W")[0])
+    q[q == w] = int(_data.encode("A")[0])
+    lengths = rng.integers(1, 320, size=900)
+    res, off = _data.random_db(rng, lengths)
+    for k in range(0, 900, 9):   # a ninth of the targets: nothing to align with
+        res[off[k]:off[k + 1]] = w
+    for k in range(4, 900, 9):   # another ninth: the query itself inside, edited
+        if lengths[k] > qlen + 8:
+            at = off[k] + rng.integers(0, lengths[k] - qlen - 4)
+            res[at:at + qlen] = q
+            res[at + qlen // 2] = w
+    got, routing = search(capi, q, res, off, B62, 3, 1, "hw")
+    assert routing & PACKED_SCAN and routing & PACKED_TRACE, routing
+    ref = _oracle.search(q, res, off, B62, 3, 1, "full", "hw")
+    compare(got, ref, "full", f"hw Q={qlen}")
+    tuning.setenv("MIOPAL_NO_PACKED_HW_SCAN", "1")
+    wide, routing = search(capi, q, res, off, B62, 3, 1, "hw")
+    assert routing & PACKED_SCAN == 0, routing
+    for key in KEYS:
+        np.testing.assert_array_equal(got[key], wide[key], err_msg=key)
