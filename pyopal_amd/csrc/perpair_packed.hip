@@ -9,7 +9,9 @@
 // from the linear database and its own bytes of the query profile in LDS (one v_perm_b32 per row puts the two
 // scores side by side).
 //
-//   perpair_packed_trace_kernel   directions of the [start..end] rectangles as bit planes
+//   perpair_packed_trace_kernel         directions of the [start..end] rectangles as bit planes (every mode)
+//   perpair_packed_scan_kernel          start cells of queries of one strip (SW; HW: the answer in the query's last row only)
+//   perpair_packed_scan_strips_kernel   ... of several strips (perpair_packed_strips.inc)
 //
 // Values are unsigned patterns compared as half floats (interseq_impl.h, "biased integer halves"): between
 // 0x0400 and 0x7BFF the order of the bit patterns is the order of the numbers, so v_pk_maximum3_f16 folds two
