@@ -171,7 +171,7 @@ struct PerPairArgs {
     // the directions leave as bit planes: [job / 64][strip][j / 4][rows 0-31 | 32-63][job % 64][plane][j % 4] dwords
     int profileStride;
     int reversed;
-    int scanLastRow;          // packed start-cell scans: the answer is in the LAST ROW of the reversed prefix (HW) instead of any cell (SW)
+    int scanLastRow;          // packed start-cell scans: 0 = any cell answers (SW), 1 = the query's last row (HW), 2 = the pair's own last row or its last column (OV)
     int64_t residueCount;     // bytes at `residues` (the profile kernel reads them four at a time, clamped; >= 4)
     // non-null (with computeUnits): the start-cell scan of a one-strip query by persistent wavefronts whose lanes take
     // the next job when they are done (perpair_scan_refill_kernel); the counter is zero at launch

@@ -66,6 +66,45 @@ static __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32
 #endif
 }
 
+// ... with a mask of the lane's own (the select trees of the OV scan)
+static __device__ __forceinline__ uint32_t bfiLane(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+// rows[] (a power-of-two-sized view: groups of eight, up to eight groups): the entry of row r of either half, r in
+// bits 0-5 / 16-21 of rs2 - a tree of selects over both halves at once, one v_bfi_b32 a node
+template <int ROWS>
+static __device__ __forceinline__ uint32_t pickRowOfEither(const uint32_t (&rows)[ROWS], uint32_t rs2) {
+    static_assert(ROWS % 8 == 0 && ROWS <= 64, "groups of eight rows");
+    auto maskOf = [&](int bit) -> uint32_t {
+        const uint32_t x = (rs2 >> bit) & 0x00010001u;
+        return (x << 16) - x;   // 0xffff in the half whose bit is set
+    };
+    uint32_t t[32];
+    const uint32_t m0 = maskOf(0);
+#pragma unroll
+    for (int k = 0; k < ROWS / 2; ++k) t[k] = bfiLane(m0, rows[2 * k + 1], rows[2 * k]);
+    const uint32_t m1 = maskOf(1);
+#pragma unroll
+    for (int k = 0; k < ROWS / 4; ++k) t[k] = bfiLane(m1, t[2 * k + 1], t[2 * k]);
+    const uint32_t m2 = maskOf(2);
+#pragma unroll
+    for (int k = 0; k < ROWS / 8; ++k) t[k] = bfiLane(m2, t[2 * k + 1], t[2 * k]);
+    constexpr int G = ROWS / 8;   // one entry per group of eight now
+    if (G == 1) return t[0];
+    // (groups that are not there are never asked for: any entry stands in for them)
+    const uint32_t m3 = maskOf(3);
+    uint32_t u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = bfiLane(m3, t[2 * k + 1 < G ? 2 * k + 1 : G - 1], t[2 * k < G ? 2 * k : G - 1]);
+    if (G <= 2) return u[0];
+    const uint32_t m4 = maskOf(4);
+    const uint32_t v0 = bfiLane(m4, u[1], u[0]), v1 = bfiLane(m4, u[3], u[2]);
+    if (G <= 4) return v0;
+    return bfiLane(maskOf(5), v1, v0);
+}
+
 // Workgroups of four wavefronts, two per CU (two wavefronts per SIMD), when their LDS fits twice - a workgroup's
 // slot is free again when its LAST wavefront is done, and eight sorted wavefronts differ by more than four - else
 // of eight.
@@ -445,8 +484,13 @@ struct ScanHalf {
     const uint8_t* tptr;
 };
 
-template <int GROUPS, bool BIASED>
-__global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPairArgs a) {
+// OV (the answer in the pair's OWN last row - the reversed prefix ends where the forward pass ended - or anywhere in its
+// last column): an instantiation of its own, its extra work (a select tree per column) is nobody else's.
+// REGION: 0 = any cell answers (SW), 1 = the query's last row (HW), 2 = OV; Smith-Waterman's instantiation holds none of the
+// others' registers (167 of them: three wavefronts per SIMD; with the last row's cell kept as well, 175 and two).
+template <int GROUPS, bool BIASED, int REGION>
+__global__ __launch_bounds__(kScanBlock, (GROUPS <= 7 && REGION == 0) ? 3 : 2) void perpair_packed_scan_kernel(PerPairArgs a) {
+    constexpr bool OV = REGION == 2;
     constexpr int ROWS = GROUPS * 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t pkLds[];
     uint8_t* const prof = pkLds;
@@ -485,8 +529,9 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) HS[i] = E[i] = top2;
     bool exhausted = false;   // wave-uniform: no pair left to take
-    const bool lastRowOnly = a.scanLastRow != 0;              // (wave-uniform)
+    constexpr bool lastRowOnly = REGION == 1;
     const int lastRowLocal = lastRowOnly ? Qtot - 1 : 0;      // one strip: the query's last row (every HW prefix has them all)
+    uint32_t rs2 = 0;                                         // OV: the halves' own last rows, 16 bits each
 
     auto fetchRaw = [&](const ScanHalf& h, int j0) -> uint32_t {
         const uint8_t* at = h.tptr - j0 - 3;
@@ -608,11 +653,13 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                     if (startA) {
                         shiftA = (uint32_t)ysA & 3u;
                         yAl2 = (yAl2 & 0xffff0000u) | (uint32_t)(ysA & ~3);
+                        if (OV) rs2 = (rs2 & 0xffff0000u) | (uint32_t)(hA.Q - 1);
                         busyA = true;
                     }
                     if (startB) {
                         shiftB = (uint32_t)ysB & 3u;
                         yAl2 = (yAl2 & 0x0000ffffu) | ((uint32_t)(ysB & ~3) << 16);
+                        if (OV) rs2 = (rs2 & 0x0000ffffu) | ((uint32_t)(hB.Q - 1) << 16);
                         busyB = true;
                     }
                     incr2 = (busyA ? (uint32_t)(8 * ext) : 0u) | (busyB ? (uint32_t)(8 * ext) << 16 : 0u);
@@ -654,7 +701,7 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
             const uint32_t e = pkMax(E[i], HS[i]);
             const uint32_t f = pkMax(F, hsUp) - ext2;
             const uint32_t h = pkMax3(d, e, f);
-            if (i >= ROWS - 8) hLast = i == lastRowLocal ? h : hLast;   // (wave-uniform)
+            if (lastRowOnly && i >= ROWS - 8) hLast = i == lastRowLocal ? h : hLast;   // (wave-uniform)
             // the group's maximum, two rows a step
             const int r = i & 7, g = i >> 3;
             if (r == 1) gm[g] = pkMax(held, h);
@@ -676,14 +723,21 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
             else cmk = pkMax(cmk, gm[g] + both(7 - g));
         }
         // (HW, scanLastRow: only the cell of the query's last row answers, and cells above it may well be larger)
-        const uint32_t x = lastRowOnly ? hLast ^ tgt2 : (cmk & 0xfff8fff8u) ^ tgt2;
+        uint32_t x = lastRowOnly ? hLast ^ tgt2 : (cmk & 0xfff8fff8u) ^ tgt2;
+        // OV: a half's last column answers in every row (no cell of the answer region exceeds the optimum, the rows beyond
+        // the pair's query are smaller still: the test above); every other column only in the pair's own last row
+        const bool lastColA = hA.j + 1 >= hA.need, lastColB = hB.j + 1 >= hB.need;
+        if (OV) {
+            const uint32_t own = pickRowOfEither<ROWS>(HS, rs2) ^ (tgt2 - c2);   // (HS holds h - c2)
+            x = (lastColA ? x & 0xffffu : own & 0xffffu) | (lastColB ? x & 0xffff0000u : own & 0xffff0000u);
+        }
         const bool hitA = busyA && (x & 0xffffu) == 0, hitB = busyB && (x >> 16) == 0;
         if (__builtin_amdgcn_ballot_w64(hitA || hitB) != 0) {
             const int gstarA = 7 - (int)(cmk & 7u), gstarB = 7 - (int)((cmk >> 16) & 7u);
-            int rowA = lastRowLocal, rowB = lastRowLocal;
+            int rowA = OV ? (int)(rs2 & 0xffffu) : lastRowLocal, rowB = OV ? (int)(rs2 >> 16) : lastRowLocal;
 #pragma unroll
             for (int g = 0; g < GROUPS && !lastRowOnly; ++g) {
-                const bool inA = hitA && gstarA == g, inB = hitB && gstarB == g;
+                const bool inA = hitA && gstarA == g && (!OV || lastColA), inB = hitB && gstarB == g && (!OV || lastColB);
                 if (__builtin_amdgcn_ballot_w64(inA || inB) == 0) continue;
                 // the first row of the group that holds the group's maximum: keys again, value + 7 - row
                 uint32_t m = pkMax(HS[8 * g] + both(7), HS[8 * g + 1] + both(6));
@@ -715,9 +769,11 @@ __global__ __launch_bounds__(kScanBlock) void perpair_packed_scan_kernel(PerPair
                     const bool found = h.bcol >= 0;
                     // (HW: the whole query in one gap before the target's first aligned residue is a border cell of the
                     // reversed problem, which no scan computes: start_cells_kernel, oracle/opal_oracle.c)
-                    const bool border = !found && lastRowOnly && stop == borderGap(h.Q - 1, open, ext);
-                    if (!found && !border) atomicExch(a.startChecks, h.out + 1);
-                    const int sq = found ? h.Q - 1 - h.brow : 0, st = found ? L - 1 - h.bcol : border ? L : 0;
+                    const bool border = !found && (lastRowOnly || OV) && stop == borderGap(h.Q - 1, open, ext);
+                    // (OV: ... or the whole target prefix in one gap: start_cells_kernel asks in this order)
+                    const bool borderT = OV && !found && !border && stop == borderGap(L - 1, open, ext);
+                    if (!found && !border && !borderT) atomicExch(a.startChecks, h.out + 1);
+                    const int sq = found ? h.Q - 1 - h.brow : borderT ? h.Q : 0, st = found ? L - 1 - h.bcol : border ? L : 0;
                     a.startQ[h.out] = sq;
                     a.startT[h.out] = st;
                     windowMax = max(windowMax, L - st);
@@ -857,10 +913,21 @@ bool packedScanFits(int queryLength, int alphabet, int open, int ext, int maxSco
 
 template <int GROUPS>
 static hipError_t launchPackedScanAs(const PerPairArgs& a, size_t ldsBytes, int blocks, hipStream_t stream) {
-    if (a.packedBias > 0)
-        hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, true>), dim3(blocks), dim3(kScanBlock), ldsBytes, stream, a);
-    else
-        hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, false>), dim3(blocks), dim3(kScanBlock), ldsBytes, stream, a);
+    const dim3 grid(blocks), block(kScanBlock);
+    const bool biased = a.packedBias > 0;
+    switch (a.scanLastRow) {
+        case 2:
+            if (biased) hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, true, 2>), grid, block, ldsBytes, stream, a);
+            else hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, false, 2>), grid, block, ldsBytes, stream, a);
+            break;
+        case 1:
+            if (biased) hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, true, 1>), grid, block, ldsBytes, stream, a);
+            else hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, false, 1>), grid, block, ldsBytes, stream, a);
+            break;
+        default:
+            if (biased) hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, true, 0>), grid, block, ldsBytes, stream, a);
+            else hipLaunchKernelGGL((perpair_packed_scan_kernel<GROUPS, false, 0>), grid, block, ldsBytes, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -884,7 +951,7 @@ hipError_t launchPerPairPackedScan(const PerPairArgs& a, size_t ldsBytes, hipStr
     if (b.refillLanes <= 0) b.refillLanes = 24;
     if (const char* e = tuned(Tune::SCAN_REFILL_LANES)) b.refillLanes = std::min(128, std::max(1, atoi(e)));   // (experiments)
     // persistent wavefronts: two per SIMD, three when the strip has up to 56 rows (167 registers)
-    int perCu = a.queryLength <= 56 ? 3 : 2;
+    int perCu = a.queryLength <= 56 && a.scanLastRow == 0 ? 3 : 2;   // (HW, OV: their extra registers leave room for two)
     if (const char* e = tuned(Tune::SCAN_BLOCKS_PER_CU)) perCu = std::max(1, std::min(atoi(e), 8));   // (experiments)
     const int blocks = std::min((waves + kScanWaves - 1) / kScanWaves, a.computeUnits * perCu);
     switch ((a.queryLength + 7) / 8) {

@@ -83,7 +83,7 @@ def test_every_mode_against_the_checker(capi, lane_per_pair, algo, matrix, go, g
         q = _data.random_protein(rng, qlen)
         got, routing = search(capi, q, res, off, matrix, go, ge, algo)
         assert routing & PACKED_TRACE, (routing, qlen)
-        assert bool(routing & PACKED_SCAN) == (algo in ("sw", "hw")), (routing, qlen)   # (OV keeps the 32-bit scan)
+        assert bool(routing & PACKED_SCAN) == (algo in ("sw", "hw") or (algo == "ov" and qlen <= 64)), (routing, qlen)
         ref = _oracle.search(q, res, off, matrix, go, ge, "full", algo)
         compare(got, ref, "full", f"{algo} Q={qlen} gaps {go}/{ge}")
 
@@ -263,9 +263,11 @@ def test_orders_and_overlaps_of_the_pipeline_do_not_change_results(capi, tuning)
         assert np.array_equal(base["aln_flat"][a0:a1], want["aln"][rank]), t
 
 
-@pytest.mark.parametrize("qlen", [53, 150])
-def test_hw_start_cells_on_the_packed_scan(capi, lane_per_pair, tuning, qlen):
-    """HW: the reversed-prefix scan answers only in the query's last row (perpair_packed.hip, scanLastRow), cells above it
+@pytest.mark.parametrize("algo,qlen", [("hw", 53), ("hw", 150), ("ov", 53), ("ov", 64), ("ov", 9)])
+def test_hw_and_ov_start_cells_on_the_packed_scan(capi, lane_per_pair, tuning, algo, qlen):
+    """OV (queries of one strip): the answer in the pair's OWN last row - the reversed prefix ends where the forward pass
+    ended, in the last row or the last column - or anywhere in its last column: a select tree over the rows per column.
+    HW: the reversed-prefix scan answers only in the query's last row (perpair_packed.hip, scanLastRow), cells above it
     may exceed the optimum (targets of tryptophans against a query without one: every real cell is worse than the query
     in one gap; the case where THAT is the optimum at a real end cell - a border cell of the reversed problem, which no
     scan computes - is the property tier's). Against the checker, and against the 32-bit scan array by array."""
@@ -282,12 +284,21 @@ def test_hw_start_cells_on_the_packed_scan(capi, lane_per_pair, tuning, qlen):
             at = off[k] + rng.integers(0, lengths[k] - qlen - 4)
             res[at:at + qlen] = q
             res[at + qlen // 2] = w
-    got, routing = search(capi, q, res, off, B62, 3, 1, "hw")
+    # (OV: targets that end inside the query, so that the forward pass ends in the last COLUMN - a copy of the query's
+    # first half at the target's end)
+    for k in range(7, 900, 9):
+        half = qlen // 2
+        if lengths[k] > half + 4 and half > 0:
+            res[off[k + 1] - half:off[k + 1]] = q[:half]
+    got, routing = search(capi, q, res, off, B62, 3, 1, algo)
     assert routing & PACKED_SCAN and routing & PACKED_TRACE, routing
-    ref = _oracle.search(q, res, off, B62, 3, 1, "full", "hw")
-    compare(got, ref, "full", f"hw Q={qlen}")
+    ref = _oracle.search(q, res, off, B62, 3, 1, "full", algo)
+    compare(got, ref, "full", f"{algo} Q={qlen}")
+    if algo == "ov":
+        ends = np.asarray(got["end_q"])
+        assert np.count_nonzero((ends >= 0) & (ends < qlen - 1)) > 20   # (pairs whose own last row is not the query's)
     tuning.setenv("MIOPAL_NO_PACKED_HW_SCAN", "1")
-    wide, routing = search(capi, q, res, off, B62, 3, 1, "hw")
+    wide, routing = search(capi, q, res, off, B62, 3, 1, algo)
     assert routing & PACKED_SCAN == 0, routing
     for key in KEYS:
         np.testing.assert_array_equal(got[key], wide[key], err_msg=key)
