@@ -940,8 +940,14 @@ hipError_t launchPerPairPackedScan(const PerPairArgs& a, size_t ldsBytes, hipStr
         // ([wavefront][column][lane] x 8 bytes, a.boundaryStride columns per wavefront)
         if (a.boundary == nullptr || a.boundaryStride <= 0 || a.jobs == nullptr) return hipErrorInvalidValue;
         const dim3 grid((waves + kScanWaves - 1) / kScanWaves), block(kScanBlock);
-        if (a.packedBias > 0) hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<true>), grid, block, ldsBytes, stream, a);
-        else hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<false>), grid, block, ldsBytes, stream, a);
+        if (a.scanLastRow == 2) {
+            if (a.packedBias > 0) hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<true, true>), grid, block, ldsBytes, stream, a);
+            else hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<false, true>), grid, block, ldsBytes, stream, a);
+        } else if (a.packedBias > 0) {
+            hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<true, false>), grid, block, ldsBytes, stream, a);
+        } else {
+            hipLaunchKernelGGL((perpair_packed_scan_strips_kernel<false, false>), grid, block, ldsBytes, stream, a);
+        }
         return hipGetLastError();
     }
     if (a.jobCounter == nullptr || a.computeUnits <= 0) return hipErrorInvalidValue;

@@ -83,7 +83,7 @@ def test_every_mode_against_the_checker(capi, lane_per_pair, algo, matrix, go, g
         q = _data.random_protein(rng, qlen)
         got, routing = search(capi, q, res, off, matrix, go, ge, algo)
         assert routing & PACKED_TRACE, (routing, qlen)
-        assert bool(routing & PACKED_SCAN) == (algo in ("sw", "hw") or (algo == "ov" and qlen <= 64)), (routing, qlen)
+        assert bool(routing & PACKED_SCAN) == (algo != "nw"), (routing, qlen)   # (NW has no scan)
         ref = _oracle.search(q, res, off, matrix, go, ge, "full", algo)
         compare(got, ref, "full", f"{algo} Q={qlen} gaps {go}/{ge}")
 
@@ -263,9 +263,9 @@ def test_orders_and_overlaps_of_the_pipeline_do_not_change_results(capi, tuning)
         assert np.array_equal(base["aln_flat"][a0:a1], want["aln"][rank]), t
 
 
-@pytest.mark.parametrize("algo,qlen", [("hw", 53), ("hw", 150), ("ov", 53), ("ov", 64), ("ov", 9)])
+@pytest.mark.parametrize("algo,qlen", [("hw", 53), ("hw", 150), ("ov", 53), ("ov", 64), ("ov", 9), ("ov", 150), ("ov", 200)])
 def test_hw_and_ov_start_cells_on_the_packed_scan(capi, lane_per_pair, tuning, algo, qlen):
-    """OV (queries of one strip): the answer in the pair's OWN last row - the reversed prefix ends where the forward pass
+    """OV: the answer in the pair's OWN last row - the reversed prefix ends where the forward pass
     ended, in the last row or the last column - or anywhere in its last column: a select tree over the rows per column.
     HW: the reversed-prefix scan answers only in the query's last row (perpair_packed.hip, scanLastRow), cells above it
     may exceed the optimum (targets of tryptophans against a query without one: every real cell is worse than the query

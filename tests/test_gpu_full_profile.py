@@ -76,10 +76,10 @@ def both_forms(capi, tuning, q, res, off, matrix, go, ge, algo="sw", expect_prof
         assert (routing & 3 == 3) == (algo != "nw"), routing
         assert bool(routing & 32) == (algo != "nw" and len(q) <= 64), routing
         if packed_applies(matrix, go, ge):
-            # the direction pass of every mode, the scan of Smith-Waterman and HW prefixes
+            # the direction pass of every mode, the scan of Smith-Waterman, HW and OV prefixes
             # (the scan when eight times its values fit the half floats as well: not gap 5/5 against 400 columns)
             assert packed_routing & 64, packed_routing
-            assert algo in ("sw", "hw") or (algo == "ov" and len(q) <= 64) or not packed_routing & 128, packed_routing
+            assert algo != "nw" or not packed_routing & 128, packed_routing   # (NW has no scan)
             assert packed_routing & 128 or algo != "sw" or ge > 1, packed_routing
         else:
             assert packed_routing & (64 | 128) == 0, packed_routing
