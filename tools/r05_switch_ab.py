@@ -1,5 +1,5 @@
 """Round 5: one switch on and off by turns in ONE process (box-to-box and run-to-run differences of `full` are larger
-than most effects). usage: r05_switch_ab.py SWITCH [N] [Q] [open] [ext] [algo]   (SWITCH without the MIOPAL_ prefix)"""
+than most effects). usage: r05_switch_ab.py SWITCH[=VALUE] [N] [Q] [open] [ext] [algo]   (SWITCH without the MIOPAL_ prefix)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,8 @@ import _data
 from pyopal_amd import _capi
 from pyopal_amd.matrices import ScoringMatrix
 
-SW = sys.argv[1]
+SW, _, VALUE = sys.argv[1].partition("=")
+VALUE = VALUE or "1"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 Q = int(sys.argv[3]) if len(sys.argv) > 3 else 53
 GO = int(sys.argv[4]) if len(sys.argv) > 4 else 3
@@ -23,7 +24,7 @@ for _ in range(3):
     r = db.search(q, m, GO, GE, "full", ALGO, reuse=r)
 meds = {"default": [], SW: []}
 for turn in range(int(os.environ.get("TURNS", "6"))):
-    for label, sw in (("default", {}), (SW, {SW: "1"})):
+    for label, sw in (("default", {}), (SW, {SW: VALUE})):
         with _capi.tuning(**sw):
             r = db.search(q, m, GO, GE, "full", ALGO, reuse=r)
             ts = []
